@@ -1,0 +1,145 @@
+/* libqtts_hip -- C ABI of the MI355X (gfx950) Qwen3-TTS inference hot path.
+ *
+ * Drop-in boundary for the `qwen_tts` crate of tardigrade-dot/qwen3-tts-rs: a `hip` feature binds these
+ * entry points (plain pointers and sizes, no C++ or torch types) in place of the Candle tensor calls
+ * made by the functions cited on each declaration.  Citations are relative to the reference checkout
+ * (qwen_tts/src/...).
+ *
+ * Conventions: every function returns 0 on success or a negative error class (QTTS_ERR_*), with a
+ * message available from qtts_last_error() (thread local).  Nothing unwinds across the boundary.  The
+ * caller owns every buffer it passes; the library owns the handles.  One qtts_ctx per GPU; a handle is
+ * not thread-safe (callers serialise per handle, different GPUs may run from different threads).  All
+ * host pointers are read / written synchronously before the call returns.
+ */
+#ifndef QTTS_H
+#define QTTS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QTTS_ERR_BAD_ARG (-1)
+#define QTTS_ERR_HIP (-2)
+#define QTTS_ERR_OOM (-3)
+#define QTTS_ERR_SHAPE (-4)
+#define QTTS_ERR_STATE (-5)
+
+#define QTTS_F32 0
+#define QTTS_BF16 1
+
+typedef struct qtts_ctx qtts_ctx;
+typedef struct qtts_model qtts_model;
+
+/* Device selection.  Replaces the Candle `Device` chosen in qwen_tts_cli/src/main.rs:138-161. */
+int qtts_init(int device_ordinal, qtts_ctx** out);
+void qtts_shutdown(qtts_ctx* ctx);
+const char* qtts_last_error(void);
+/* The HIP stream (hipStream_t) every kernel of this context is launched on; for event timing. */
+void* qtts_stream(qtts_ctx* ctx);
+
+/* Model construction.  Replaces ModelLoader::load_tts_model (model/loader.rs:267-324):
+ * config_json is the text of config.json (config/tts_config.rs:15), codec_config_json the text of
+ * speech_tokenizer/config.json (audio/tokenizer/v2/config.rs:9) or NULL for a model without codec.
+ * dtype: QTTS_F32 or QTTS_BF16 (LoaderConfig.dtype, model/loader.rs:31-54). */
+int qtts_model_create(qtts_ctx* ctx, const char* config_json, const char* codec_config_json, int dtype,
+                      qtts_model** out);
+/* One safetensors tensor, by its HF key (the VarBuilder paths of nn/talker.rs:32-59,253-277,
+ * nn/code_predictor.rs:40-63,199-226, nn/speaker_encoder.rs:489-538, audio/decoder/v2.rs:53-134; codec
+ * keys carry the "decoder." prefix of speech_tokenizer/model.safetensors).  data is host memory in
+ * src_dtype (QTTS_F32 / QTTS_BF16); the library converts, uploads and later fuses (q|k|v, gate|up). */
+int qtts_model_load_tensor(qtts_model* m, const char* hf_key, const void* data, int src_dtype, const int64_t* shape,
+                           int rank);
+/* Same, with `data` already resident in this GPU's memory (synthetic benchmarks; no reference counterpart). */
+int qtts_model_load_tensor_device(qtts_model* m, const char* hf_key, const void* data, int src_dtype,
+                                  const int64_t* shape, int rank);
+/* Checks that every tensor the configs require is present, builds fused weights, RoPE tables and the
+ * normalised codebooks (audio/quantizer.rs:56-59). */
+int qtts_model_finalize(qtts_model* m);
+void qtts_model_free(qtts_model* m);
+
+/* One utterance.  Mirrors GenerationOptions (nn/generation_options.rs) + the text ids handed to
+ * ConditionalGeneration::generate (nn/generation.rs:815). */
+typedef struct {
+    const uint32_t* text_ids;      /* <|im_start|>assistant\n ... <|im_end|>\n<|im_start|>assistant\n  */
+    int n_text;
+    const uint32_t* instruct_ids;  /* optional, NULL / 0 */
+    int n_instruct;
+    const char* language;          /* "auto", "english", ... (generation.rs:452-498) */
+    const char* speaker;           /* name in talker_config.spk_id, or NULL */
+    const float* speaker_embed;    /* optional x-vector, hidden_size floats (generation.rs:540-550) */
+    const uint32_t* ref_codes;     /* optional ICL reference codes [ref_T][num_code_groups] */
+    int ref_T;
+    const uint32_t* ref_text_ids;  /* optional ICL reference text */
+    int n_ref_text;
+    int non_streaming;             /* GenerationOptions.non_streaming_mode (default 1) */
+    int use_seed;                  /* 0: draws come from a time-seeded stream (nn/mt_rng.rs:204-214) */
+    uint64_t seed;                 /* MT19937 seed of this utterance's draw stream (nn/mt_rng.rs:196) */
+} qtts_request;
+
+/* SamplingConfig (nn/sampling.rs:13-64) as merged by GenerateConfig::merge (model/config.rs:128-157). */
+typedef struct {
+    float temperature;
+    int top_k;
+    float top_p;
+    int do_sample;
+    float repetition_penalty;
+    int subtalker_do_sample;
+    float subtalker_temperature;
+    int subtalker_top_k;
+    float subtalker_top_p;
+} qtts_sampling;
+
+/* Output{codes, num_steps, effective_lengths} (nn/generation.rs:31-38) for one utterance.
+ * codes: caller-allocated max_new_tokens * num_code_groups u32, filled as [num_steps][groups]. */
+typedef struct {
+    uint32_t* codes;
+    int num_steps;
+    int effective_len;
+} qtts_codes_out;
+
+/* Optional per-step traces for parity tests (NULL pointers are skipped); each is caller-allocated for
+ * max_new_tokens steps of utterance 0..n-1: logits [n][max_new][vocab], hidden [n][max_new][hidden]. */
+typedef struct {
+    float* logits;
+    float* hidden;
+    int use_graph;     /* 1: replay the decode frame as a hipGraph (default path), 0: eager launches */
+    int profile_gemm;  /* eager only: time every weight-streaming GEMM launch with HIP events */
+} qtts_gen_debug;
+
+/* ConditionalGeneration::generate (nn/generation.rs:815-1194) for n independent utterances decoded as
+ * one batch; row i is token-identical to a batch-1 call with reqs[i] (rows never interact). */
+int qtts_generate(qtts_model* m, const qtts_request* reqs, int n, const qtts_sampling* s, int max_new_tokens,
+                  qtts_codes_out* outs);
+int qtts_generate_ex(qtts_model* m, const qtts_request* reqs, int n, const qtts_sampling* s, int max_new_tokens,
+                     qtts_codes_out* outs, const qtts_gen_debug* dbg);
+
+/* Timing of the last qtts_generate_ex call (milliseconds, HIP events on the context stream):
+ * out[0] prompt+prefill, out[1] frame loop, out[2] summed GEMM kernel time (profile_gemm only),
+ * out[3] GEMM launches timed, out[4] algorithmic weight bytes those launches streamed. */
+int qtts_last_timing(qtts_model* m, double* out, int n);
+
+/* Model::decode_output / TokenizerV2::{decode,chunked_decode} (model/generate.rs:29-143,
+ * audio/tokenizer/v2/mod.rs:208-232, audio/decoder/v2.rs:163-286).  codes [B][T_max][Q]; lens[b] frames
+ * of row b are decoded; chunk <= 0 decodes whole sequences, chunk > 0 uses the reference's chunked
+ * decode (windows of `chunk` frames with `left_ctx` frames of left context), chunk == -2 applies the
+ * decode_output policy (> 512 frames => 256/32).  wav_out [B][wav_stride] floats; wav_lens[b] receives
+ * the number of samples produced for row b. */
+int qtts_codec_decode(qtts_model* m, const uint32_t* codes, const int* lens, int B, int T_max, int chunk, int left_ctx,
+                      float* wav_out, int64_t wav_stride, int64_t* wav_lens);
+
+/* mel_spectrogram (audio/mel.rs:81-158, default config) as used by Model::compute_mel_spectrogram
+ * (model/mod.rs:520-528): audio [B][max_samples] f32 @ 24 kHz -> mel_out [B][frames_stride][128]. */
+int qtts_mel(qtts_model* m, const float* audio, const int* n_samples, int B, int max_samples, float* mel_out,
+             int frames_stride, int* n_frames);
+/* ConditionalGeneration::encode_speaker (nn/generation.rs:140) on top of qtts_mel: emb_out [B][enc_dim]. */
+int qtts_speaker_embed(qtts_model* m, const float* audio, const int* n_samples, int B, int max_samples, float* emb_out);
+
+/* Shape queries a binding needs to size its buffers. */
+int qtts_model_info(qtts_model* m, int* hidden, int* vocab, int* groups, int* total_upsample, int* enc_dim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QTTS_H */

@@ -1,0 +1,164 @@
+// C ABI of libqtts_hip (declared in include/qtts.h).  Exceptions never cross the boundary: they are
+// mapped to the negative error classes and a thread-local message.
+#include <cstring>
+#include <string>
+
+#include "generate.hpp"
+
+using namespace qtts;
+
+struct qtts_ctx {
+    Ctx c;
+};
+struct qtts_model {
+    Model m;
+};
+
+namespace {
+thread_local std::string g_err;
+int fail(const std::exception& e, int code) {
+    g_err = e.what();
+    return code;
+}
+}  // namespace
+
+#define QTTS_API_BEGIN try {
+#define QTTS_API_END                                  \
+    return 0;                                         \
+    }                                                 \
+    catch (const qtts::Error& e) {                    \
+        return fail(e, e.code);                       \
+    }                                                 \
+    catch (const std::bad_alloc& e) {                 \
+        return fail(e, ERR_OOM);                      \
+    }                                                 \
+    catch (const std::exception& e) {                 \
+        return fail(e, ERR_STATE);                    \
+    }
+
+extern "C" {
+
+const char* qtts_last_error(void) { return g_err.c_str(); }
+
+int qtts_init(int device_ordinal, qtts_ctx** out) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(out != nullptr, ERR_BAD_ARG, "qtts_init: null out");
+    int count = 0;
+    QTTS_HIP(hipGetDeviceCount(&count));
+    QTTS_CHECK(device_ordinal >= 0 && device_ordinal < count, ERR_BAD_ARG, "qtts_init: no such device");
+    QTTS_HIP(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    QTTS_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+    QTTS_CHECK(std::string(prop.gcnArchName).rfind("gfx950", 0) == 0, ERR_STATE,
+               std::string("qtts_init: kernels are built for gfx950 only, found ") + prop.gcnArchName);
+    qtts_ctx* c = new qtts_ctx();
+    c->c.device = device_ordinal;
+    QTTS_HIP(hipStreamCreateWithFlags(&c->c.stream, hipStreamNonBlocking));
+    *out = c;
+    QTTS_API_END
+}
+
+void qtts_shutdown(qtts_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->c.stream) (void)hipStreamDestroy(ctx->c.stream);
+    delete ctx;
+}
+
+void* qtts_stream(qtts_ctx* ctx) { return ctx ? (void*)ctx->c.stream : nullptr; }
+
+int qtts_model_create(qtts_ctx* ctx, const char* config_json, const char* codec_config_json, int dtype, qtts_model** out) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(ctx && config_json && out, ERR_BAD_ARG, "qtts_model_create: null argument");
+    QTTS_CHECK(dtype == F32 || dtype == BF16, ERR_BAD_ARG, "qtts_model_create: dtype must be QTTS_F32 or QTTS_BF16");
+    std::unique_ptr<qtts_model> m(new qtts_model());
+    m->m.ctx = &ctx->c;
+    m->m.dtype = dtype;
+    m->m.parse_config(config_json, codec_config_json);
+    *out = m.release();
+    QTTS_API_END
+}
+
+int qtts_model_load_tensor(qtts_model* m, const char* hf_key, const void* data, int src_dtype, const int64_t* shape, int rank) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(m && hf_key && shape, ERR_BAD_ARG, "qtts_model_load_tensor: null argument");
+    m->m.load_tensor(hf_key, data, src_dtype, shape, rank, false);
+    QTTS_API_END
+}
+
+int qtts_model_load_tensor_device(qtts_model* m, const char* hf_key, const void* data, int src_dtype, const int64_t* shape,
+                                  int rank) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(m && hf_key && shape, ERR_BAD_ARG, "qtts_model_load_tensor_device: null argument");
+    m->m.load_tensor(hf_key, data, src_dtype, shape, rank, true);
+    QTTS_API_END
+}
+
+int qtts_model_finalize(qtts_model* m) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(m, ERR_BAD_ARG, "qtts_model_finalize: null model");
+    m->m.finalize();
+    QTTS_API_END
+}
+
+void qtts_model_free(qtts_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->m.ctx->device);
+    (void)hipDeviceSynchronize();
+    delete m;
+}
+
+int qtts_generate_ex(qtts_model* m, const qtts_request* reqs, int n, const qtts_sampling* s, int max_new_tokens,
+                     qtts_codes_out* outs, const qtts_gen_debug* dbg) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(m, ERR_BAD_ARG, "qtts_generate: null model");
+    run_generate(m->m, reqs, n, s, max_new_tokens, outs, dbg);
+    QTTS_API_END
+}
+
+int qtts_generate(qtts_model* m, const qtts_request* reqs, int n, const qtts_sampling* s, int max_new_tokens,
+                  qtts_codes_out* outs) {
+    return qtts_generate_ex(m, reqs, n, s, max_new_tokens, outs, nullptr);
+}
+
+int qtts_last_timing(qtts_model* m, double* out, int n) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(m && out && n >= 0, ERR_BAD_ARG, "qtts_last_timing: null argument");
+    for (int i = 0; i < n && i < 8; ++i) out[i] = m->m.timing[i];
+    QTTS_API_END
+}
+
+int qtts_codec_decode(qtts_model* m, const uint32_t* codes, const int* lens, int B, int T_max, int chunk, int left_ctx,
+                      float* wav_out, int64_t wav_stride, int64_t* wav_lens) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(m && codes && lens && wav_out && wav_lens, ERR_BAD_ARG, "qtts_codec_decode: null argument");
+    run_codec_decode(m->m, codes, lens, B, T_max, chunk, left_ctx, wav_out, wav_stride, wav_lens);
+    QTTS_API_END
+}
+
+int qtts_mel(qtts_model* m, const float* audio, const int* n_samples, int B, int max_samples, float* mel_out, int frames_stride,
+             int* n_frames) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(m && audio && n_samples && mel_out && n_frames, ERR_BAD_ARG, "qtts_mel: null argument");
+    run_mel(m->m, audio, n_samples, B, max_samples, mel_out, frames_stride, n_frames);
+    QTTS_API_END
+}
+
+int qtts_speaker_embed(qtts_model* m, const float* audio, const int* n_samples, int B, int max_samples, float* emb_out) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(m && audio && n_samples && emb_out, ERR_BAD_ARG, "qtts_speaker_embed: null argument");
+    run_speaker_embed(m->m, audio, n_samples, B, max_samples, emb_out);
+    QTTS_API_END
+}
+
+int qtts_model_info(qtts_model* m, int* hidden, int* vocab, int* groups, int* total_upsample, int* enc_dim) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(m, ERR_BAD_ARG, "qtts_model_info: null model");
+    if (hidden) *hidden = m->m.cfg.talker.hidden;
+    if (vocab) *vocab = m->m.cfg.vocab;
+    if (groups) *groups = m->m.cfg.groups;
+    if (total_upsample) *total_upsample = m->m.codec.present ? m->m.codec.total_upsample() : 0;
+    if (enc_dim) *enc_dim = m->m.cfg.has_speaker_encoder ? m->m.cfg.enc_dim : 0;
+    QTTS_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,603 @@
+// ConditionalGeneration::generate on the GPU (qwen_tts/src/nn/generation.rs:815-1194) for a batch of
+// independent utterances: prompt embedding assembly (:510-799), talker prefill, then one hipGraph
+// replay per generated frame covering the talker decode step, cb0 sampling, the G-1 code-predictor
+// passes (nn/code_predictor.rs:433-531) and the next-input embedding sum.  No host round trip
+// happens inside a frame; the host only polls the per-row EOS steps every few frames.
+#include "generate.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+namespace qtts {
+
+namespace {
+
+constexpr int PAGE_TOKENS = 64;      // talker KV page (positions per page)
+constexpr int CP_PAGE_TOKENS = 64;   // one page holds a whole code-predictor context (<= groups + 1)
+constexpr int PREFILL_CHUNK = 256;   // prompt tokens per prefill pass
+constexpr int EOS_POLL = 8;          // frames between host checks of the EOS flags
+
+struct HostMT {  // MT19937 (rand_mt `Mt::new(seed as u32)`), 24-bit uniforms (nn/mt_rng.rs:64-81)
+    uint32_t mt[624];
+    int idx = 624;
+    explicit HostMT(uint32_t seed) {
+        mt[0] = seed;
+        for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    }
+    uint32_t next() {
+        if (idx >= 624) {
+            for (int i = 0; i < 624; ++i) {
+                const uint32_t y = (mt[i] & 0x80000000u) | (mt[(i + 1) % 624] & 0x7fffffffu);
+                mt[i] = mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+            }
+            idx = 0;
+        }
+        uint32_t y = mt[idx++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+    float uniform() { return (float)(next() & 0x00FFFFFFu) / 16777216.0f; }
+};
+
+std::string lower(const char* s) {
+    std::string r = s ? s : "";
+    for (auto& c : r) c = (char)std::tolower((unsigned char)c);
+    return r;
+}
+
+struct GemmPlan {
+    int N, K, KS;
+};
+
+}  // namespace
+
+struct StackRun {
+    DevBuf pool, table;
+    KVView kv{};
+    int layers = 0;
+};
+
+struct GenState {
+    // activations (token-major rows)
+    DevBuf x, xn, part, q, attn, act;       // residual f32 | gemm input T | split-K partials f32 | q f32 | attn T | mlp act T
+    DevBuf cp_in_t, cp_in_f, hid_scratch_f; // code-predictor inputs; rows [0,B) double as the talker's post-norm hidden
+    DevBuf text_rows, extra, trailing, tts_pad_dummy;
+    DevBuf ibuf;                             // int scratch: ids / descriptors
+    DevBuf toks_prompt, toks_dec, toks_cp;
+    DevBuf row_len, step, eos_step, hist, uniforms, codes, trailing_len;
+    DevBuf trace_logits, trace_hidden;
+    StackRun talker, cp;
+    size_t cap_rows = 0;
+    // GEMM event timing
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    double gemm_bytes = 0;
+    bool profile = false;
+    hipGraphExec_t graph_exec = nullptr;
+    ~GenState() {
+        for (auto e : ev) (void)hipEventDestroy(e);
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    }
+};
+
+namespace {
+
+struct Runner {
+    Model& m;
+    GenState& g;
+    hipStream_t st;
+    int dt;
+    size_t es;
+
+    Runner(Model& model, GenState& gs) : m(model), g(gs), st(model.ctx->stream), dt(model.dtype), es(dtype_size(model.dtype)) {}
+
+    void gemm(const void* W, const void* X, int M, int N, int K, int KS, int ldx) {
+        if (g.profile && g.ev_used + 2 <= 400000) {
+            while (g.ev.size() < g.ev_used + 2) {
+                hipEvent_t e;
+                QTTS_HIP(hipEventCreate(&e));
+                g.ev.push_back(e);
+            }
+            QTTS_HIP(hipEventRecord(g.ev[g.ev_used], st));
+            launch_gemm(st, dt, W, X, g.part.as<float>(), M, N, K, KS, ldx);
+            QTTS_HIP(hipEventRecord(g.ev[g.ev_used + 1], st));
+            g.ev_used += 2;
+            g.gemm_bytes += (double)N * K * es;
+        } else {
+            launch_gemm(st, dt, W, X, g.part.as<float>(), M, N, K, KS, ldx);
+        }
+    }
+    long kstride(int M, int N) const { return (long)gemm_pad_rows(M) * N; }
+
+    // One decoder layer over M tokens (nn/decoder_layer.rs:63-86).  On entry x holds the residual
+    // stream and xn = RMSNorm_ln1(x); on exit xn = RMSNorm_next(x) with `next_norm` the following
+    // layer's input norm (or the stack's final norm).
+    void layer(const StackW& s, int l, int M, const Tok* toks, const KVView& kv, const float* next_norm, void* xn_out,
+               float* xn_f32_out) {
+        const StackCfg& c = s.cfg;
+        const LayerW& w = s.layers[(size_t)l];
+        const int nq = c.nh * c.d, nqkv = (c.nh + 2 * c.nkv) * c.d;
+        int ks = gemm_pick_ks(M, nqkv, c.hidden, dt);
+        gemm(w.qkv, g.xn.p, M, nqkv, c.hidden, ks, c.hidden);
+        QkvPostArgs qa{};
+        qa.part = g.part.as<float>(); qa.KS = ks; qa.ks_stride = kstride(M, nqkv); qa.bias = w.qkv_bias;
+        qa.q_norm = w.q_norm; qa.k_norm = w.k_norm; qa.eps = c.eps; qa.cos = s.cos.as<float>(); qa.sin = s.sin.as<float>();
+        qa.rope_mode = 0; qa.toks = toks; qa.M = M; qa.nh = c.nh; qa.nkv = c.nkv; qa.d = c.d; qa.layer = l;
+        qa.q_out = g.q.as<float>();
+        launch_qkv_post(st, dt, qa, kv);
+        launch_attention(st, dt, g.q.as<float>(), toks, kv, l, M, c.nh, (float)std::pow((double)c.d, -0.5), g.attn.p);
+        ks = gemm_pick_ks(M, c.hidden, nq, dt);
+        gemm(w.o, g.attn.p, M, c.hidden, nq, ks, nq);
+        launch_resid_norm(st, dt, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), w.o_bias, w.ln2, c.eps,
+                          g.x.as<float>(), g.xn.p, nullptr, M, c.hidden);
+        ks = gemm_pick_ks(M, 2 * c.inter, c.hidden, dt);
+        gemm(w.gate_up, g.xn.p, M, 2 * c.inter, c.hidden, ks, c.hidden);
+        launch_swiglu(st, dt, g.part.as<float>(), ks, kstride(M, 2 * c.inter), g.act.p, M, c.inter);
+        ks = gemm_pick_ks(M, c.hidden, c.inter, dt);
+        gemm(w.down, g.act.p, M, c.hidden, c.inter, ks, c.inter);
+        launch_resid_norm(st, dt, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), nullptr, next_norm, c.eps,
+                          g.x.as<float>(), xn_out, xn_f32_out, M, c.hidden);
+    }
+
+    void stack(const StackW& s, int M, const Tok* toks, const KVView& kv, void* final_xn, float* final_xn_f32) {
+        for (int l = 0; l < s.cfg.layers; ++l) {
+            const bool last = l + 1 == s.cfg.layers;
+            layer(s, l, M, toks, kv, last ? s.final_norm : s.layers[(size_t)l + 1].ln1, last ? final_xn : g.xn.p,
+                  last ? final_xn_f32 : nullptr);
+        }
+    }
+};
+
+}  // namespace
+
+void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling* sp, int max_new, qtts_codes_out* outs,
+                  const qtts_gen_debug* dbg) {
+    QTTS_CHECK(m.finalized && m.codec_head != nullptr, ERR_STATE, "generate: model has no talker weights or is not finalized");
+    QTTS_CHECK(reqs && outs && sp && n >= 1 && n <= 1024, ERR_BAD_ARG, "generate: bad batch");
+    QTTS_CHECK(max_new >= 1 && max_new <= 32768, ERR_BAD_ARG, "generate: max_new_tokens out of range");
+    QTTS_HIP(hipSetDevice(m.ctx->device));
+    const ModelCfg& c = m.cfg;
+    const int B = n, H = c.talker.hidden, Ht = c.text_hidden, G = c.groups, V = c.vocab, Vc = c.cp_vocab, Hc = c.cp.hidden;
+    if (!m.gen) m.gen.reset(new GenState());
+    GenState& g = *m.gen;
+    Runner R(m, g);
+    hipStream_t st = R.st;
+    const int dt = m.dtype;
+    const size_t es = R.es;
+    const bool use_graph = dbg ? dbg->use_graph != 0 : true;
+    g.profile = dbg && dbg->profile_gemm && !use_graph;
+    g.ev_used = 0;
+    g.gemm_bytes = 0;
+
+    // ------------------------------------------------------------------ host-side prompt planning
+    std::vector<int> text_ids = {c.tts_bos, c.tts_eos, c.tts_pad};  // rows 0,1,2 of the projected-text buffer
+    auto add_text = [&](uint32_t id) {
+        QTTS_CHECK((int)id < c.text_vocab, ERR_BAD_ARG, "generate: text id outside the text vocabulary");
+        text_ids.push_back((int)id);
+        return (int)text_ids.size() - 1;
+    };
+    std::vector<int> p_text, p_codec, p_extra;  // flattened prompt position descriptors
+    std::vector<Tok> p_toks;
+    std::vector<int> row_P(B), trail_len(B, 0);
+    std::vector<std::vector<int>> trail_idx((size_t)B);
+    std::vector<float> extra_rows;
+    for (int b = 0; b < B; ++b) {
+        const qtts_request& r = reqs[b];
+        QTTS_CHECK(r.text_ids && r.n_text >= 4, ERR_BAD_ARG, "generate: text_ids needs at least 4 tokens");
+        QTTS_CHECK(r.ref_T == 0 && r.ref_codes == nullptr, ERR_BAD_ARG, "generate: ICL reference codes are not supported yet");
+        // build_codec_prefill (generation.rs:452-498)
+        std::string lang = lower(r.language ? r.language : "auto");
+        const std::string spk = lower(r.speaker);
+        if ((lang == "chinese" || lang == "auto") && !spk.empty()) {
+            auto it = c.spk_dialect.find(spk);
+            if (it != c.spk_dialect.end()) lang = lower(it->second.c_str());
+        }
+        std::vector<int> ci;  // codec-side ids; -2 marks the external speaker vector
+        auto lit = c.language_id.find(lang);
+        if (lang != "auto" && lit != c.language_id.end()) ci = {c.think, c.think_bos, lit->second, c.think_eos};
+        else ci = {c.nothink, c.think_bos, c.think_eos};
+        int extra_row = -1;
+        if (r.speaker_embed) {
+            extra_row = (int)(extra_rows.size() / (size_t)H);
+            extra_rows.insert(extra_rows.end(), r.speaker_embed, r.speaker_embed + H);
+            ci.push_back(-2);
+        } else if (!spk.empty()) {
+            auto sit = c.spk_id.find(spk);
+            if (sit != c.spk_id.end()) ci.push_back(sit->second);
+        }
+        ci.push_back(c.pad);
+        ci.push_back(c.bos);
+        const int L = (int)ci.size();
+        const size_t first = p_text.size();
+        auto push = [&](int t, int cd, int ex) { p_text.push_back(t); p_codec.push_back(cd); p_extra.push_back(ex); };
+        auto codec_part = [&](int i, int& cd, int& ex) {
+            if (ci[(size_t)i] == -2) { cd = -1; ex = extra_row; }
+            else { cd = ci[(size_t)i]; ex = -1; }
+        };
+        for (int i = 0; i < r.n_instruct; ++i) push(add_text(r.instruct_ids[i]), -1, -1);
+        for (int i = 0; i < 3; ++i) push(add_text(r.text_ids[i]), -1, -1);
+        for (int i = 0; i < L - 1; ++i) {
+            int cd, ex;
+            codec_part(i, cd, ex);
+            push(i < L - 2 ? 2 : 0, cd, ex);
+        }
+        if (r.non_streaming && r.n_text > 8) {
+            for (int i = 3; i < r.n_text - 5; ++i) push(add_text(r.text_ids[i]), c.pad, -1);
+            push(1, c.pad, -1);
+            push(2, c.bos, -1);
+        } else {
+            int cd, ex;
+            codec_part(L - 1, cd, ex);
+            push(add_text(r.text_ids[3]), cd, ex);
+            if (r.n_text > 9) {
+                for (int i = 4; i < r.n_text - 5; ++i) trail_idx[(size_t)b].push_back(add_text(r.text_ids[i]));
+                trail_idx[(size_t)b].push_back(1);
+            }
+        }
+        trail_len[(size_t)b] = (int)trail_idx[(size_t)b].size();
+        row_P[(size_t)b] = (int)(p_text.size() - first);
+        for (int p = 0; p < row_P[(size_t)b]; ++p) {
+            Tok t;
+            t.row = b;
+            t.pos = p;
+            t.ctx_start = c.talker.window > 0 ? std::max(0, p + 1 - c.talker.window) : 0;
+            t.ctx_len = p + 1 - t.ctx_start;
+            p_toks.push_back(t);
+        }
+    }
+    const int Ttot = (int)p_toks.size(), Nt = (int)text_ids.size();
+    int Tt_max = 1;
+    for (int b = 0; b < B; ++b) Tt_max = std::max(Tt_max, trail_len[(size_t)b]);
+    int max_ctx = 0;
+    for (int b = 0; b < B; ++b) max_ctx = std::max(max_ctx, row_P[(size_t)b] + max_new);
+
+    // ------------------------------------------------------------------ workspace
+    const int chunk_rows = std::max(PREFILL_CHUNK, gemm_pad_rows(2 * B));
+    const size_t rows = (size_t)chunk_rows + 64;
+    const int Wmax = std::max({H, Ht, Hc});
+    const int QD = std::max({c.talker.nh * c.talker.d, c.cp.nh * c.cp.d, H, Hc});
+    const int Imax = std::max({c.talker.inter, c.cp.inter, Ht, H, Hc});
+    const int Nmax = std::max({(c.talker.nh + 2 * c.talker.nkv) * c.talker.d, (c.cp.nh + 2 * c.cp.nkv) * c.cp.d, 2 * c.talker.inter,
+                               2 * c.cp.inter, V, Vc, H, Ht, Hc});
+    g.x.ensure(rows * Wmax * 4);
+    g.xn.ensure(rows * Wmax * es);
+    g.part.ensure(rows * (size_t)Nmax * 4 * 16);  // up to 16 split-K slabs
+    g.q.ensure(rows * QD * 4);
+    g.attn.ensure(rows * QD * es);
+    g.act.ensure(rows * Imax * es);
+    const size_t cp_rows = (size_t)gemm_pad_rows(2 * B) + 64;
+    g.cp_in_t.ensure(cp_rows * H * es);
+    g.cp_in_f.ensure(cp_rows * H * 4);
+    g.text_rows.ensure((size_t)Nt * H * 4);
+    g.extra.ensure(std::max<size_t>(extra_rows.size(), 1) * 4);
+    g.trailing.ensure((size_t)B * Tt_max * H * 4);
+    g.ibuf.ensure(((size_t)Ttot * 3 + Nt + (size_t)B * Tt_max + 4 * B + 64) * 4);
+    g.toks_prompt.ensure((size_t)Ttot * sizeof(Tok));
+    g.toks_dec.ensure((size_t)B * sizeof(Tok));
+    g.toks_cp.ensure((size_t)(2 * B + (size_t)B * G) * sizeof(Tok));
+    g.row_len.ensure((size_t)B * 4);
+    g.step.ensure(16);
+    g.eos_step.ensure((size_t)B * 4);
+    g.hist.ensure((size_t)B * V * 4);
+    g.uniforms.ensure((size_t)B * max_new * G * 4);
+    g.codes.ensure((size_t)B * max_new * G * 4);
+    g.trailing_len.ensure((size_t)B * 4);
+    m.ensure_rope(m.talker, max_ctx + 1);
+    m.ensure_rope(m.cp, G + 2);
+
+    // KV pools
+    {
+        const int max_pages = (max_ctx + PAGE_TOKENS - 1) / PAGE_TOKENS;
+        std::vector<int> table((size_t)B * max_pages, 0);
+        int next = 0;
+        for (int b = 0; b < B; ++b) {
+            const int np = (row_P[(size_t)b] + max_new + PAGE_TOKENS - 1) / PAGE_TOKENS;
+            for (int i = 0; i < np; ++i) table[(size_t)b * max_pages + i] = next++;
+        }
+        const size_t page_elems = (size_t)2 * c.talker.nkv * PAGE_TOKENS * c.talker.d;
+        g.talker.pool.ensure((size_t)c.talker.layers * next * page_elems * es);
+        g.talker.table.ensure(table.size() * 4);
+        QTTS_HIP(hipMemcpyAsync(g.talker.table.p, table.data(), table.size() * 4, hipMemcpyHostToDevice, st));
+        g.talker.kv = KVView{g.talker.pool.p, (size_t)next * page_elems, PAGE_TOKENS, c.talker.nkv, c.talker.d, max_pages,
+                             g.talker.table.as<int>()};
+        QTTS_CHECK(G + 1 <= CP_PAGE_TOKENS, ERR_SHAPE, "generate: too many code groups for the code-predictor KV page");
+        std::vector<int> cpt((size_t)B);
+        for (int b = 0; b < B; ++b) cpt[(size_t)b] = b;
+        const size_t cpage = (size_t)2 * c.cp.nkv * CP_PAGE_TOKENS * c.cp.d;
+        g.cp.pool.ensure((size_t)c.cp.layers * B * cpage * es);
+        g.cp.table.ensure((size_t)B * 4);
+        QTTS_HIP(hipMemcpyAsync(g.cp.table.p, cpt.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+        g.cp.kv = KVView{g.cp.pool.p, (size_t)B * cpage, CP_PAGE_TOKENS, c.cp.nkv, c.cp.d, 1, g.cp.table.as<int>()};
+        QTTS_HIP(hipStreamSynchronize(st));  // the host vectors above go out of scope
+    }
+
+    // uniforms in the reference's draw order per utterance: frame by frame, cb0 first then codebooks 1..G-1
+    // (generation.rs:1055-1060, code_predictor.rs:468-472,517-522); a greedy stage consumes no draw.
+    if (sp->do_sample || sp->subtalker_do_sample) {
+        std::vector<float> u((size_t)B * max_new * G, 0.f);
+        for (int b = 0; b < B; ++b) {
+            uint64_t seed = reqs[b].seed;
+            if (!reqs[b].use_seed)
+                seed = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                           std::chrono::system_clock::now().time_since_epoch()).count() + (uint64_t)b * 0x9E3779B97F4A7C15ull;
+            HostMT rng((uint32_t)seed);
+            for (int s = 0; s < max_new; ++s) {
+                float* row = &u[((size_t)b * max_new + s) * G];
+                if (sp->do_sample) row[0] = rng.uniform();
+                if (sp->subtalker_do_sample)
+                    for (int j = 1; j < G; ++j) row[j] = rng.uniform();
+            }
+        }
+        QTTS_HIP(hipMemcpy(g.uniforms.p, u.data(), u.size() * 4, hipMemcpyHostToDevice));
+    }
+
+    hipEvent_t ev0, ev1, ev2;
+    QTTS_HIP(hipEventCreate(&ev0));
+    QTTS_HIP(hipEventCreate(&ev1));
+    QTTS_HIP(hipEventCreate(&ev2));
+    QTTS_HIP(hipEventRecord(ev0, st));
+
+    // ------------------------------------------------------------------ upload descriptors
+    int* ib = g.ibuf.as<int>();
+    int* d_ptext = ib;
+    int* d_pcodec = ib + Ttot;
+    int* d_pextra = ib + 2 * Ttot;
+    int* d_textids = ib + 3 * Ttot;
+    int* d_trail = d_textids + Nt;
+    int* d_last_src = d_trail + B * Tt_max;
+    int* d_last_dst = d_last_src + B;
+    QTTS_HIP(hipMemcpyAsync(d_ptext, p_text.data(), (size_t)Ttot * 4, hipMemcpyHostToDevice, st));
+    QTTS_HIP(hipMemcpyAsync(d_pcodec, p_codec.data(), (size_t)Ttot * 4, hipMemcpyHostToDevice, st));
+    QTTS_HIP(hipMemcpyAsync(d_pextra, p_extra.data(), (size_t)Ttot * 4, hipMemcpyHostToDevice, st));
+    QTTS_HIP(hipMemcpyAsync(d_textids, text_ids.data(), (size_t)Nt * 4, hipMemcpyHostToDevice, st));
+    std::vector<int> trail_flat((size_t)B * Tt_max, 2);
+    for (int b = 0; b < B; ++b)
+        for (size_t i = 0; i < trail_idx[(size_t)b].size(); ++i) trail_flat[(size_t)b * Tt_max + i] = trail_idx[(size_t)b][i];
+    QTTS_HIP(hipMemcpyAsync(d_trail, trail_flat.data(), trail_flat.size() * 4, hipMemcpyHostToDevice, st));
+    QTTS_HIP(hipMemcpyAsync(g.toks_prompt.p, p_toks.data(), (size_t)Ttot * sizeof(Tok), hipMemcpyHostToDevice, st));
+    QTTS_HIP(hipMemcpyAsync(g.trailing_len.p, trail_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    QTTS_HIP(hipMemcpyAsync(g.row_len.p, row_P.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
+    if (!extra_rows.empty()) QTTS_HIP(hipMemcpyAsync(g.extra.p, extra_rows.data(), extra_rows.size() * 4, hipMemcpyHostToDevice, st));
+    QTTS_HIP(hipMemsetAsync(g.step.p, 0, 16, st));
+    QTTS_HIP(hipMemsetAsync(g.eos_step.p, 0xff, (size_t)B * 4, st));
+    QTTS_HIP(hipMemsetAsync(g.hist.p, 0, (size_t)B * V * 4, st));
+    QTTS_HIP(hipMemsetAsync(g.codes.p, 0, (size_t)B * max_new * G * 4, st));
+    // code-predictor token descriptors: pass 0 = 2B tokens (position-major), unmasked => both attend 2 keys
+    // (code_predictor.rs:455-460 + attention/mod.rs:413-417); pass j = B tokens at position j + 1.
+    {
+        std::vector<Tok> ct((size_t)2 * B + (size_t)B * G);
+        for (int p = 0; p < 2; ++p)
+            for (int b = 0; b < B; ++b) ct[(size_t)p * B + b] = Tok{b, p, 0, 2};
+        for (int j = 1; j < G - 1; ++j)
+            for (int b = 0; b < B; ++b) ct[(size_t)2 * B + (size_t)j * B + b] = Tok{b, j + 1, 0, j + 2};
+        QTTS_HIP(hipMemcpyAsync(g.toks_cp.p, ct.data(), ct.size() * sizeof(Tok), hipMemcpyHostToDevice, st));
+        QTTS_HIP(hipStreamSynchronize(st));
+    }
+
+    // ------------------------------------------------------------------ text projection (talker.rs:345-348, mlp.rs:149-160)
+    for (int o = 0; o < Nt; o += chunk_rows) {
+        const int M = std::min(chunk_rows, Nt - o);
+        launch_gather_rows(st, m.text_emb, dt, d_textids + o, g.xn.p, dt, M, Ht, Ht);
+        int ks = gemm_pick_ks(M, Ht, Ht, dt);
+        R.gemm(m.fc1, g.xn.p, M, Ht, Ht, ks, Ht);
+        launch_bias_act(st, g.part.as<float>(), ks, R.kstride(M, Ht), m.fc1_b, 1, g.act.p, dt, M, Ht);
+        ks = gemm_pick_ks(M, H, Ht, dt);
+        R.gemm(m.fc2, g.act.p, M, H, Ht, ks, Ht);
+        launch_bias_act(st, g.part.as<float>(), ks, R.kstride(M, H), m.fc2_b, 0, g.text_rows.as<float>() + (size_t)o * H, F32, M, H);
+    }
+    launch_gather_rows(st, g.text_rows.p, F32, d_trail, g.trailing.p, F32, B * Tt_max, H, H);
+    const float* tts_pad_row = g.text_rows.as<float>() + (size_t)2 * H;
+
+    // ------------------------------------------------------------------ prefill (generation.rs:884-903)
+    void* hid_t = g.cp_in_t.p;                 // rows [0,B): post-norm hidden of each row's newest position
+    float* hid_f = g.cp_in_f.as<float>();
+    {
+        std::vector<int> last_src, last_dst;
+        int row_end = 0;
+        std::vector<int> ends((size_t)B);
+        for (int b = 0; b < B; ++b) { row_end += row_P[(size_t)b]; ends[(size_t)b] = row_end - 1; }
+        for (int o = 0; o < Ttot; o += chunk_rows) {
+            const int M = std::min(chunk_rows, Ttot - o);
+            launch_assemble(st, g.text_rows.as<float>(), d_ptext + o, m.codec_emb, dt, d_pcodec + o, g.extra.as<float>(),
+                            d_pextra + o, g.x.as<float>(), M, H);
+            launch_resid_norm(st, dt, g.x.as<float>(), nullptr, 0, 0, nullptr, m.talker.layers[0].ln1, c.talker.eps, g.x.as<float>(),
+                              g.xn.p, nullptr, M, H);
+            // final norm output reuses act (T) and q (f32) as scratch rows
+            R.stack(m.talker, M, g.toks_prompt.as<Tok>() + o, g.talker.kv, g.act.p, g.q.as<float>());
+            last_src.clear();
+            last_dst.clear();
+            for (int b = 0; b < B; ++b)
+                if (ends[(size_t)b] >= o && ends[(size_t)b] < o + M) { last_src.push_back(ends[(size_t)b] - o); last_dst.push_back(b); }
+            if (!last_src.empty()) {
+                const int nl = (int)last_src.size();
+                QTTS_HIP(hipMemcpyAsync(d_last_src, last_src.data(), (size_t)nl * 4, hipMemcpyHostToDevice, st));
+                QTTS_HIP(hipMemcpyAsync(d_last_dst, last_dst.data(), (size_t)nl * 4, hipMemcpyHostToDevice, st));
+                launch_copy_rows(st, g.act.p, d_last_src, hid_t, d_last_dst, dt, nl, H);
+                launch_copy_rows(st, g.q.p, d_last_src, hid_f, d_last_dst, F32, nl, H);
+                QTTS_HIP(hipStreamSynchronize(st));  // last_src/last_dst are reused by the next chunk
+            }
+        }
+    }
+    QTTS_HIP(hipEventRecord(ev1, st));
+
+    // ------------------------------------------------------------------ frame pieces
+    const bool trace_l = dbg && dbg->logits, trace_h = dbg && dbg->hidden;
+    if (trace_l) g.trace_logits.ensure((size_t)B * max_new * V * 4);
+    if (trace_h) g.trace_hidden.ensure((size_t)B * max_new * H * 4);
+    const long row_stride = (long)max_new * G;
+    int* d_step = g.step.as<int>();
+
+    auto sample = [&](const float* logits, int vocab, int gcol, bool talker) {
+        SampleArgs a{};
+        a.logits = logits; a.V = vocab; a.B = B;
+        const double T = talker ? sp->temperature : sp->subtalker_temperature;
+        a.temperature = T == 1.0 ? 1.0f : (float)(1.0 / T);
+        a.top_k = talker ? sp->top_k : sp->subtalker_top_k;
+        a.top_p = talker ? sp->top_p : sp->subtalker_top_p;
+        a.do_sample = talker ? sp->do_sample : sp->subtalker_do_sample;
+        a.rep_penalty = talker ? sp->repetition_penalty : 1.0f;
+        a.hist_count = talker && sp->repetition_penalty != 1.0f ? g.hist.as<int>() : nullptr;
+        a.suppress_lo = talker ? std::max(0, V - 1024) : 0;
+        a.suppress_hi = talker ? V : 0;
+        a.eos_id = talker ? c.eos : -1;
+        a.min_new_tokens = talker ? 2 : 0;  // sampling.rs:55 via generation.rs:841-842; subtalker: sampling.rs:117
+        a.step = d_step; a.uniforms = g.uniforms.as<float>(); a.codes_base = g.codes.as<unsigned>(); a.row_stride = row_stride;
+        a.G = G; a.g = gcol; a.eos_step = talker ? g.eos_step.as<int>() : nullptr;
+        launch_sample(st, a);
+    };
+
+    // logits -> cb0 -> code predictor -> next talker input (generation.rs:1029-1106)
+    auto frame_tail = [&](bool eager_trace) {
+        R.gemm(m.codec_head, hid_t, B, V, H, 1, H);
+        if (eager_trace && trace_l) {
+            // step index is only known on the device; trace copies use the host's mirror of it
+        }
+        sample(g.part.as<float>(), V, 0, true);
+        // ---- code predictor pass 0: [hidden, embed(cb0)] at positions 0, 1
+        const Tok* ct = g.toks_cp.as<Tok>();
+        if (m.proj) {
+            launch_gather_codes(st, m.codec_emb, dt, g.codes.as<unsigned>(), row_stride, d_step, G, 0, (char*)g.cp_in_t.p + (size_t)B * H * es, dt, B, H);
+            const int ks = gemm_pick_ks(2 * B, Hc, H, dt);
+            R.gemm(m.proj, g.cp_in_t.p, 2 * B, Hc, H, ks, H);
+            launch_resid_norm(st, dt, nullptr, g.part.as<float>(), ks, R.kstride(2 * B, Hc), m.proj_b, m.cp.layers[0].ln1, c.cp.eps,
+                              g.x.as<float>(), g.xn.p, nullptr, 2 * B, Hc);
+        } else {
+            launch_gather_codes(st, m.codec_emb, dt, g.codes.as<unsigned>(), row_stride, d_step, G, 0, g.cp_in_f.as<float>() + (size_t)B * H, F32, B, H);
+            launch_resid_norm(st, dt, nullptr, g.cp_in_f.as<float>(), 1, 0, nullptr, m.cp.layers[0].ln1, c.cp.eps, g.x.as<float>(),
+                              g.xn.p, nullptr, 2 * B, Hc);
+        }
+        R.stack(m.cp, 2 * B, ct, g.cp.kv, g.xn.p, nullptr);
+        R.gemm(m.cp_head[0], (char*)g.xn.p + (size_t)B * Hc * es, B, Vc, Hc, 1, Hc);
+        sample(g.part.as<float>(), Vc, 1, false);
+        for (int j = 1; j < G - 1; ++j) {  // code_predictor.rs:480-527
+            if (m.proj) {
+                launch_gather_codes(st, m.cp_emb[(size_t)j - 1], dt, g.codes.as<unsigned>(), row_stride, d_step, G, j, g.act.p, dt, B, H);
+                const int ks = gemm_pick_ks(B, Hc, H, dt);
+                R.gemm(m.proj, g.act.p, B, Hc, H, ks, H);
+                launch_resid_norm(st, dt, nullptr, g.part.as<float>(), ks, R.kstride(B, Hc), m.proj_b, m.cp.layers[0].ln1, c.cp.eps,
+                                  g.x.as<float>(), g.xn.p, nullptr, B, Hc);
+            } else {
+                launch_gather_codes(st, m.cp_emb[(size_t)j - 1], dt, g.codes.as<unsigned>(), row_stride, d_step, G, j, g.q.p, F32, B, H);
+                launch_resid_norm(st, dt, nullptr, g.q.as<float>(), 1, 0, nullptr, m.cp.layers[0].ln1, c.cp.eps, g.x.as<float>(), g.xn.p,
+                                  nullptr, B, Hc);
+            }
+            R.stack(m.cp, B, ct + 2 * B + (size_t)j * B, g.cp.kv, g.xn.p, nullptr);
+            R.gemm(m.cp_head[(size_t)j], g.xn.p, B, Vc, Hc, 1, Hc);
+            sample(g.part.as<float>(), Vc, j + 1, false);
+        }
+        // ---- next talker input (talker.rs:461-479 + generation.rs:1096-1106) and its layer-0 norm
+        EmbedSumArgs ea{};
+        ea.codec_emb = m.codec_emb; ea.cp_emb = (const void* const*)m.cp_emb_ptrs.p; ea.edtype = dt;
+        ea.codes_base = g.codes.as<unsigned>(); ea.row_stride = row_stride; ea.step = d_step;
+        ea.trailing = g.trailing.as<float>(); ea.trailing_len = g.trailing_len.as<int>(); ea.Tt_max = Tt_max;
+        ea.tts_pad = tts_pad_row; ea.G = G; ea.H = H; ea.B = B;
+        launch_embed_sum_norm(st, dt, ea, m.talker.layers[0].ln1, c.talker.eps, g.x.as<float>(), g.xn.p);
+        launch_advance_step(st, d_step);
+    };
+    auto talker_step = [&]() {  // generation.rs:1002-1026
+        launch_make_decode_toks(st, g.row_len.as<int>(), g.toks_dec.as<Tok>(), B, c.talker.window);
+        R.stack(m.talker, B, g.toks_dec.as<Tok>(), g.talker.kv, hid_t, hid_f);
+    };
+    auto trace_copy = [&](int step) {
+        // logits of this frame are recomputed into the partial buffer by frame_tail; hidden is in hid_f
+        if (trace_h)
+            QTTS_HIP(hipMemcpy2DAsync(g.trace_hidden.as<float>() + (size_t)step * H, (size_t)max_new * H * 4, hid_f, (size_t)H * 4,
+                                      (size_t)H * 4, B, hipMemcpyDeviceToDevice, st));
+        if (trace_l) {
+            R.gemm(m.codec_head, hid_t, B, V, H, 1, H);
+            QTTS_HIP(hipMemcpy2DAsync(g.trace_logits.as<float>() + (size_t)step * V, (size_t)max_new * V * 4, g.part.p, (size_t)V * 4,
+                                      (size_t)V * 4, B, hipMemcpyDeviceToDevice, st));
+        }
+    };
+
+    // ------------------------------------------------------------------ frame loop
+    std::vector<int> eos((size_t)B, -1);
+    int steps_done = 0;
+    auto all_eos = [&]() {
+        QTTS_HIP(hipMemcpyAsync(eos.data(), g.eos_step.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+        QTTS_HIP(hipStreamSynchronize(st));
+        for (int b = 0; b < B; ++b)
+            if (eos[(size_t)b] < 0) return false;
+        return true;
+    };
+    const bool tracing = trace_l || trace_h;
+    if (tracing) trace_copy(0);
+    frame_tail(false);
+    steps_done = 1;
+    hipGraph_t graph = nullptr;
+    if (use_graph && !tracing && max_new > 1) {
+        if (g.graph_exec) { (void)hipGraphExecDestroy(g.graph_exec); g.graph_exec = nullptr; }
+        QTTS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        try {
+            talker_step();
+            frame_tail(false);
+        } catch (...) {
+            hipGraph_t junk = nullptr;
+            (void)hipStreamEndCapture(st, &junk);
+            if (junk) (void)hipGraphDestroy(junk);
+            throw;
+        }
+        QTTS_HIP(hipStreamEndCapture(st, &graph));
+        QTTS_HIP(hipGraphInstantiate(&g.graph_exec, graph, nullptr, nullptr, 0));
+        QTTS_HIP(hipGraphDestroy(graph));
+    }
+    bool done = false;
+    while (steps_done < max_new && !done) {
+        if (steps_done % EOS_POLL == 0 && all_eos()) { done = true; break; }
+        if (g.graph_exec && use_graph && !tracing) {
+            QTTS_HIP(hipGraphLaunch(g.graph_exec, st));
+        } else {
+            talker_step();
+            if (tracing) trace_copy(steps_done);
+            frame_tail(false);
+        }
+        ++steps_done;
+    }
+    QTTS_HIP(hipEventRecord(ev2, st));
+    all_eos();
+    QTTS_HIP(hipGetLastError());
+
+    // ------------------------------------------------------------------ results (generation.rs:1125-1193)
+    // The reference stops one step after every row has produced EOS; rows keep generating until then.
+    bool every = true;
+    int last_eos = -1;
+    for (int b = 0; b < B; ++b) {
+        if (eos[(size_t)b] < 0 || eos[(size_t)b] >= steps_done) { every = false; eos[(size_t)b] = -1; }
+        else last_eos = std::max(last_eos, eos[(size_t)b]);
+    }
+    const int num_steps = every ? std::min(steps_done, last_eos + 1) : steps_done;
+    std::vector<uint32_t> hcodes((size_t)B * max_new * G);
+    QTTS_HIP(hipMemcpy(hcodes.data(), g.codes.p, hcodes.size() * 4, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b) {
+        outs[b].num_steps = num_steps;
+        outs[b].effective_len = (eos[(size_t)b] >= 0 && eos[(size_t)b] < num_steps) ? eos[(size_t)b] : num_steps;
+        if (outs[b].codes) std::memcpy(outs[b].codes, &hcodes[(size_t)b * max_new * G], (size_t)num_steps * G * 4);
+    }
+    if (trace_l) QTTS_HIP(hipMemcpy(dbg->logits, g.trace_logits.p, (size_t)B * max_new * V * 4, hipMemcpyDeviceToHost));
+    if (trace_h) QTTS_HIP(hipMemcpy(dbg->hidden, g.trace_hidden.p, (size_t)B * max_new * H * 4, hipMemcpyDeviceToHost));
+    float ms01 = 0, ms12 = 0;
+    QTTS_HIP(hipEventElapsedTime(&ms01, ev0, ev1));
+    QTTS_HIP(hipEventElapsedTime(&ms12, ev1, ev2));
+    m.timing[0] = ms01;
+    m.timing[1] = ms12;
+    double gemm_ms = 0;
+    for (size_t i = 0; i + 1 < g.ev_used; i += 2) {
+        float t = 0;
+        QTTS_HIP(hipEventElapsedTime(&t, g.ev[i], g.ev[i + 1]));
+        gemm_ms += t;
+    }
+    m.timing[2] = gemm_ms;
+    m.timing[3] = (double)(g.ev_used / 2);
+    m.timing[4] = g.gemm_bytes;
+    m.timing[5] = (double)steps_done;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    (void)hipEventDestroy(ev2);
+}
+
+}  // namespace qtts

@@ -1,0 +1,20 @@
+// Entry points implemented per subsystem (generate.cpp, codec.cpp, speaker.cpp).
+#pragma once
+#include "../../include/qtts.h"
+#include "model.hpp"
+
+namespace qtts {
+
+void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling* s, int max_new_tokens, qtts_codes_out* outs,
+                  const qtts_gen_debug* dbg);
+
+void finalize_codec(Model& m);
+void run_codec_decode(Model& m, const uint32_t* codes, const int* lens, int B, int T_max, int chunk, int left_ctx, float* wav_out,
+                      int64_t wav_stride, int64_t* wav_lens);
+
+void finalize_speaker(Model& m);
+void run_mel(Model& m, const float* audio, const int* n_samples, int B, int max_samples, float* mel_out, int frames_stride,
+             int* n_frames);
+void run_speaker_embed(Model& m, const float* audio, const int* n_samples, int B, int max_samples, float* emb_out);
+
+}  // namespace qtts

@@ -1,0 +1,191 @@
+// Attention for tokens in flight over a paged KV cache (gfx950).
+//
+// qkv_post: split-K combine of the fused q|k|v projection, per-head RMSNorm on q and k, RoPE, KV append
+//   (qwen_tts/src/nn/attention/unified.rs:193-216, nn/rope/mod.rs:46-62, nn/kv_cache.rs:38-42).
+// attention: GQA softmax(q k^T * scale) v for one token against its row's cached keys
+//   (nn/attention/mod.rs:359-472; the additive 0/-inf masks become the key range in Tok).
+// Both are HBM-bound: K/V are read once, straight to registers with 16-byte loads (8 head dims per
+// lane, D/8 lanes per key), online softmax in f32, one block per (token, kv head).
+#include "device_utils.hpp"
+#include "kernels.hpp"
+
+namespace qtts {
+
+template <typename T>
+__device__ __forceinline__ T* kv_ptr(const KVView& kv, int layer, int row, int pos, int which, int g) {
+    const int page = kv.page_table[(long)row * kv.max_pages + pos / kv.page_tokens];
+    const int slot = pos % kv.page_tokens;
+    return (T*)kv.base + (size_t)layer * kv.layer_stride +
+           ((((size_t)page * 2 + which) * kv.nkv + g) * kv.page_tokens + slot) * kv.d;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void qkv_post_kernel(QkvPostArgs a, KVView kv) {
+    const int m = blockIdx.x, hi = blockIdx.y, lane = threadIdx.x;
+    const int d = a.d, half = d >> 1;
+    const int ncol = (a.nh + 2 * a.nkv) * d;
+    const Tok t = a.toks[m];
+    const bool act = lane < half;
+    const int i = act ? lane : 0;
+    const long col = (long)hi * d + i;
+    float x1 = 0.f, x2 = 0.f;
+    for (int k = 0; k < a.KS; ++k) {
+        const float* p = a.part + k * a.ks_stride + (long)m * ncol + col;
+        x1 += p[0];
+        x2 += p[half];
+    }
+    if (a.bias) {
+        x1 += a.bias[col];
+        x2 += a.bias[col + half];
+    }
+    const bool is_q = hi < a.nh, is_k = !is_q && hi < a.nh + a.nkv;
+    if (is_q || is_k) {
+        const float* nw = is_q ? a.q_norm : a.k_norm;
+        if (nw) {
+            const float ss = wave_sum(act ? x1 * x1 + x2 * x2 : 0.f);
+            const float mm = sqrtf(ss / (float)d + a.eps);
+            x1 = x1 / mm * nw[i];
+            x2 = x2 / mm * nw[i + half];
+        }
+        const float c = a.cos[(long)t.pos * half + i], s = a.sin[(long)t.pos * half + i];
+        const float y1 = x1 * c - x2 * s;
+        const float y2 = x1 * s + x2 * c;
+        x1 = y1;
+        x2 = y2;
+    }
+    if (!act) return;
+    if (is_q) {
+        float* q = a.q_out + (long)m * a.nh * d + (long)hi * d;
+        q[i] = x1;
+        q[i + half] = x2;
+    } else {
+        const int g = is_k ? hi - a.nh : hi - a.nh - a.nkv;
+        T* dst = kv_ptr<T>(kv, a.layer, t.row, t.pos, is_k ? 0 : 1, g);
+        dst[i] = from_f32<T>(x1);
+        dst[i + half] = from_f32<T>(x2);
+    }
+}
+
+void launch_qkv_post(hipStream_t st, int dtype, const QkvPostArgs& a, const KVView& kv) {
+    QTTS_CHECK(a.d == 64 || a.d == 128, ERR_SHAPE, "qkv_post: head_dim must be 64 or 128");
+    QTTS_CHECK(a.M >= 1 && a.nh >= 1 && a.nkv >= 1 && kv.d == a.d && kv.nkv == a.nkv, ERR_SHAPE, "qkv_post: bad shape");
+    dim3 grid(a.M, a.nh + 2 * a.nkv);
+    if (dtype == BF16) hipLaunchKernelGGL(qkv_post_kernel<bf16_t>, grid, dim3(64), 0, st, a, kv);
+    else hipLaunchKernelGGL(qkv_post_kernel<float>, grid, dim3(64), 0, st, a, kv);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D, int REP>
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, const Tok* __restrict__ toks, KVView kv,
+                                                        int layer, int nh, float scale, T* out) {
+    constexpr int LPK = D / 8;     // lanes per key (8 head dims each)
+    constexpr int KPW = 64 / LPK;  // keys per wave per iteration
+    __shared__ float sm[4][REP][LPK][10];
+    const int m = blockIdx.x, g = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gi = lane / LPK, li = lane % LPK;
+    const Tok t = toks[m];
+
+    float qv[REP][8], o[REP][8], mx[REP], l[REP];
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+        const float* qp = q + ((long)m * nh + (long)g * REP + h) * D + li * 8;
+        load8(qp, qv[h]);
+        mx[h] = -1e30f;
+        l[h] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[h][e] = 0.f;
+    }
+
+    for (int base = wave * KPW; base < t.ctx_len; base += 4 * KPW) {
+        const int key = base + gi;
+        const bool valid = key < t.ctx_len;
+        const int pos = t.ctx_start + (valid ? key : 0);
+        const T* kp = kv_ptr<T>(kv, layer, t.row, pos, 0, g) + li * 8;
+        const T* vp = kv_ptr<T>(kv, layer, t.row, pos, 1, g) + li * 8;
+        float kf[8], vf[8];
+        load8(kp, kf);
+        load8(vp, vf);
+#pragma unroll
+        for (int h = 0; h < REP; ++h) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += qv[h][e] * kf[e];
+#pragma unroll
+            for (int off = LPK / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            s = valid ? s * scale : -INFINITY;
+            const float mn = fmaxf(mx[h], s);
+            const float alpha = expf(mx[h] - mn);
+            const float p = expf(s - mn);
+            l[h] = l[h] * alpha + p;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[h][e] = o[h][e] * alpha + p * vf[e];
+            mx[h] = mn;
+        }
+    }
+    // merge the KPW key groups of this wave
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+#pragma unroll
+        for (int off = LPK; off < 64; off <<= 1) {
+            const float mo = __shfl_xor(mx[h], off, 64), lo = __shfl_xor(l[h], off, 64);
+            const float mn = fmaxf(mx[h], mo);
+            const float a1 = expf(mx[h] - mn), a2 = expf(mo - mn);
+            l[h] = l[h] * a1 + lo * a2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[h][e] = o[h][e] * a1 + __shfl_xor(o[h][e], off, 64) * a2;
+            mx[h] = mn;
+        }
+        if (gi == 0) {
+            sm[wave][h][li][0] = mx[h];
+            sm[wave][h][li][1] = l[h];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sm[wave][h][li][2 + e] = o[h][e];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < REP * LPK) {
+        const int h = threadIdx.x / LPK, j = threadIdx.x % LPK;
+        float mn = sm[0][h][j][0];
+        for (int w = 1; w < 4; ++w) mn = fmaxf(mn, sm[w][h][j][0]);
+        float lt = 0.f, ot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int w = 0; w < 4; ++w) {
+            const float aw = expf(sm[w][h][j][0] - mn);
+            lt += sm[w][h][j][1] * aw;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ot[e] += sm[w][h][j][2 + e] * aw;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ot[e] = ot[e] / lt;
+        store8(out + ((long)m * nh + (long)g * REP + h) * D + j * 8, ot);
+    }
+}
+
+template <typename T, int D>
+static void launch_attn_rep(hipStream_t st, const float* q, const Tok* toks, const KVView& kv, int layer, int M, int nh,
+                            float scale, T* out) {
+    const int rep = nh / kv.nkv;
+    dim3 grid(M, kv.nkv), block(256);
+    switch (rep) {
+        case 1: hipLaunchKernelGGL((attention_kernel<T, D, 1>), grid, block, 0, st, q, toks, kv, layer, nh, scale, out); break;
+        case 2: hipLaunchKernelGGL((attention_kernel<T, D, 2>), grid, block, 0, st, q, toks, kv, layer, nh, scale, out); break;
+        case 4: hipLaunchKernelGGL((attention_kernel<T, D, 4>), grid, block, 0, st, q, toks, kv, layer, nh, scale, out); break;
+        case 8: hipLaunchKernelGGL((attention_kernel<T, D, 8>), grid, block, 0, st, q, toks, kv, layer, nh, scale, out); break;
+        default: throw Error(ERR_SHAPE, "attention: heads per kv head must be 1, 2, 4 or 8");
+    }
+}
+
+void launch_attention(hipStream_t st, int dtype, const float* q, const Tok* toks, const KVView& kv, int layer, int M, int nh,
+                      float scale, void* out) {
+    QTTS_CHECK(kv.d == 64 || kv.d == 128, ERR_SHAPE, "attention: head_dim must be 64 or 128");
+    QTTS_CHECK(M >= 1 && nh % kv.nkv == 0, ERR_SHAPE, "attention: bad head counts");
+    if (dtype == BF16) {
+        if (kv.d == 128) launch_attn_rep<bf16_t, 128>(st, q, toks, kv, layer, M, nh, scale, (bf16_t*)out);
+        else launch_attn_rep<bf16_t, 64>(st, q, toks, kv, layer, M, nh, scale, (bf16_t*)out);
+    } else {
+        if (kv.d == 128) launch_attn_rep<float, 128>(st, q, toks, kv, layer, M, nh, scale, (float*)out);
+        else launch_attn_rep<float, 64>(st, q, toks, kv, layer, M, nh, scale, (float*)out);
+    }
+}
+
+}  // namespace qtts

@@ -1,0 +1,264 @@
+// Row-wise / element-wise kernels of the decode path: split-K combine + residual + RMSNorm, SwiGLU,
+// bias/activation epilogues, embedding gathers and the per-frame bookkeeping that lets a whole frame
+// live inside one hipGraph.  All are HBM/L2-bound byte movers: one 256-thread block per token row,
+// float4 accesses, deterministic reduction order.
+#include "device_utils.hpp"
+#include "kernels.hpp"
+
+namespace qtts {
+
+// ------------------------------------------------------------------------------------------------
+// RMSNorm tail shared by the row producers: x (f32, already stored at xrow) -> xn = x / m * w with
+// m = sqrt(mean(x^2) + eps)   (qwen_tts/src/nn/norm.rs:17-23 -> candle_nn::rms_norm: (x / m) * w).
+template <typename T>
+__device__ __forceinline__ void rmsnorm_tail(const float* xrow, float ss_local, const float* __restrict__ w, float eps,
+                                             T* xn_row, float* xn_f32_row, int H, float* red) {
+    const float ss = block_sum(ss_local, red);
+    const float m = sqrtf(ss / (float)H + eps);
+    for (int i = threadIdx.x * 4; i < H; i += blockDim.x * 4) {
+        const float4 x = *reinterpret_cast<const float4*>(xrow + i);
+        const float4 g = *reinterpret_cast<const float4*>(w + i);
+        float4 y = make_float4(x.x / m * g.x, x.y / m * g.y, x.z / m * g.z, x.w / m * g.w);
+        if (xn_f32_row) *reinterpret_cast<float4*>(xn_f32_row + i) = y;
+        xn_row[i] = from_f32<T>(y.x);
+        xn_row[i + 1] = from_f32<T>(y.y);
+        xn_row[i + 2] = from_f32<T>(y.z);
+        xn_row[i + 3] = from_f32<T>(y.w);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void resid_norm_kernel(const float* __restrict__ resid, const float* __restrict__ part,
+                                                         int KS, long ks_stride, const float* __restrict__ bias,
+                                                         const float* __restrict__ norm_w, float eps, float* resid_out,
+                                                         T* xn, float* xn_f32, int H) {
+    __shared__ float red[32];
+    const long row = blockIdx.x;
+    float ss = 0.f;
+    for (int i = threadIdx.x * 4; i < H; i += blockDim.x * 4) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (part) {
+            s = *reinterpret_cast<const float4*>(part + row * H + i);
+            for (int k = 1; k < KS; ++k) {
+                const float4 p = *reinterpret_cast<const float4*>(part + k * ks_stride + row * H + i);
+                s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+            }
+        }
+        if (bias) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + i);
+            s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+        }
+        if (resid) {
+            const float4 r = *reinterpret_cast<const float4*>(resid + row * H + i);
+            s.x = r.x + s.x; s.y = r.y + s.y; s.z = r.z + s.z; s.w = r.w + s.w;
+        }
+        *reinterpret_cast<float4*>(resid_out + row * H + i) = s;
+        ss += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
+    }
+    if (norm_w) rmsnorm_tail<T>(resid_out + row * H, ss, norm_w, eps, xn + row * H, xn_f32 ? xn_f32 + row * H : nullptr, H, red);
+}
+
+void launch_resid_norm(hipStream_t st, int dtype, const float* resid, const float* part, int KS, long ks_stride,
+                       const float* bias, const float* norm_w, float eps, float* resid_out, void* xn, float* xn_f32, int M,
+                       int H) {
+    QTTS_CHECK(H % 4 == 0 && M >= 1, ERR_SHAPE, "resid_norm: H must be a multiple of 4");
+    QTTS_CHECK(resid_out != nullptr && (norm_w == nullptr || xn != nullptr), ERR_BAD_ARG, "resid_norm: null output");
+    if (dtype == BF16)
+        hipLaunchKernelGGL(resid_norm_kernel<bf16_t>, dim3(M), dim3(256), 0, st, resid, part, KS, ks_stride, bias, norm_w, eps,
+                           resid_out, (bf16_t*)xn, xn_f32, H);
+    else
+        hipLaunchKernelGGL(resid_norm_kernel<float>, dim3(M), dim3(256), 0, st, resid, part, KS, ks_stride, bias, norm_w, eps,
+                           resid_out, (float*)xn, xn_f32, H);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_kernel(const float* __restrict__ part, int KS, long ks_stride, T* act, int I,
+                                                     long total4) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (long)gridDim.x * blockDim.x) {
+        const long row = (e * 4) / I;
+        const int i = (int)((e * 4) % I);
+        const float* pg = part + row * 2 * I + i;
+        float4 g = *reinterpret_cast<const float4*>(pg);
+        float4 u = *reinterpret_cast<const float4*>(pg + I);
+        for (int k = 1; k < KS; ++k) {
+            const float4 g2 = *reinterpret_cast<const float4*>(pg + k * ks_stride);
+            const float4 u2 = *reinterpret_cast<const float4*>(pg + k * ks_stride + I);
+            g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
+            u.x += u2.x; u.y += u2.y; u.z += u2.z; u.w += u2.w;
+        }
+        T* o = act + row * I + i;
+        o[0] = from_f32<T>(g.x / (1.0f + expf(-g.x)) * u.x);
+        o[1] = from_f32<T>(g.y / (1.0f + expf(-g.y)) * u.y);
+        o[2] = from_f32<T>(g.z / (1.0f + expf(-g.z)) * u.z);
+        o[3] = from_f32<T>(g.w / (1.0f + expf(-g.w)) * u.w);
+    }
+}
+
+void launch_swiglu(hipStream_t st, int dtype, const float* part, int KS, long ks_stride, void* act, int M, int I) {
+    QTTS_CHECK(I % 4 == 0 && M >= 1, ERR_SHAPE, "swiglu: I must be a multiple of 4");
+    const long total4 = (long)M * I / 4;
+    const int blocks = (int)std::min<long>((total4 + 255) / 256, 2048);
+    if (dtype == BF16) hipLaunchKernelGGL(swiglu_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, part, KS, ks_stride, (bf16_t*)act, I, total4);
+    else hipLaunchKernelGGL(swiglu_kernel<float>, dim3(blocks), dim3(256), 0, st, part, KS, ks_stride, (float*)act, I, total4);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void bias_act_kernel(const float* __restrict__ part, int KS, long ks_stride,
+                                                       const float* __restrict__ bias, int act, T* out, int N, long total) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        float s = part[e];
+        for (int k = 1; k < KS; ++k) s += part[k * ks_stride + e];
+        if (bias) s += bias[e % N];
+        if (act == 1) s = s / (1.0f + expf(-s));
+        out[e] = from_f32<T>(s);
+    }
+}
+
+void launch_bias_act(hipStream_t st, const float* part, int KS, long ks_stride, const float* bias, int act, void* out,
+                     int out_dtype, int M, int N) {
+    const long total = (long)M * N;
+    const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+    if (out_dtype == BF16) hipLaunchKernelGGL(bias_act_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, part, KS, ks_stride, bias, act, (bf16_t*)out, N, total);
+    else hipLaunchKernelGGL(bias_act_kernel<float>, dim3(blocks), dim3(256), 0, st, part, KS, ks_stride, bias, act, (float*)out, N, total);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const TS* __restrict__ table, const int* __restrict__ idx, TD* dst,
+                                                          int H, long dst_ld) {
+    const long row = blockIdx.x;
+    const TS* src = table + (long)idx[row] * H;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) dst[row * dst_ld + i] = from_f32<TD>(to_f32<TS>(src[i]));
+}
+
+void launch_gather_rows(hipStream_t st, const void* table, int tdtype, const int* idx, void* dst, int ddtype, int M, int H,
+                        long dst_ld) {
+    QTTS_CHECK(M >= 1 && H >= 1, ERR_SHAPE, "gather_rows: empty");
+    dim3 g(M), b(256);
+    if (tdtype == BF16 && ddtype == BF16) hipLaunchKernelGGL((gather_rows_kernel<bf16_t, bf16_t>), g, b, 0, st, (const bf16_t*)table, idx, (bf16_t*)dst, H, dst_ld);
+    else if (tdtype == BF16) hipLaunchKernelGGL((gather_rows_kernel<bf16_t, float>), g, b, 0, st, (const bf16_t*)table, idx, (float*)dst, H, dst_ld);
+    else if (ddtype == BF16) hipLaunchKernelGGL((gather_rows_kernel<float, bf16_t>), g, b, 0, st, (const float*)table, idx, (bf16_t*)dst, H, dst_ld);
+    else hipLaunchKernelGGL((gather_rows_kernel<float, float>), g, b, 0, st, (const float*)table, idx, (float*)dst, H, dst_ld);
+}
+
+template <typename TE>
+__global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__ text_rows, const int* __restrict__ text_idx,
+                                                       const TE* __restrict__ codec_emb, const int* __restrict__ codec_id,
+                                                       const float* __restrict__ extra, const int* __restrict__ extra_idx,
+                                                       float* out, int H) {
+    const long row = blockIdx.x;
+    const int ti = text_idx[row], ci = codec_id[row], xi = extra_idx[row];
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        // the reference adds the text layer and the codec layer: text + codec (generation.rs:593,723,728,755)
+        float v = 0.f;
+        bool have = false;
+        if (ti >= 0) { v = text_rows[(long)ti * H + i]; have = true; }
+        if (ci >= 0) { const float c = to_f32<TE>(codec_emb[(long)ci * H + i]); v = have ? v + c : c; have = true; }
+        if (xi >= 0) { const float c = extra[(long)xi * H + i]; v = have ? v + c : c; }
+        out[row * H + i] = v;
+    }
+}
+
+void launch_assemble(hipStream_t st, const float* text_rows, const int* text_idx, const void* codec_emb, int edtype,
+                     const int* codec_id, const float* extra, const int* extra_idx, float* out, int M, int H) {
+    QTTS_CHECK(M >= 1, ERR_SHAPE, "assemble: empty prompt");
+    if (edtype == BF16) hipLaunchKernelGGL(assemble_kernel<bf16_t>, dim3(M), dim3(256), 0, st, text_rows, text_idx, (const bf16_t*)codec_emb, codec_id, extra, extra_idx, out, H);
+    else hipLaunchKernelGGL(assemble_kernel<float>, dim3(M), dim3(256), 0, st, text_rows, text_idx, (const float*)codec_emb, codec_id, extra, extra_idx, out, H);
+}
+
+// ------------------------------------------------------------------------------------------------
+// sum_code_embeddings (qwen_tts/src/nn/talker.rs:461-479) + trailing text / tts_pad
+// (nn/generation.rs:1096-1106) + the next layer-0 input norm.  Adds run in codebook order in f32.
+template <typename TE, typename T>
+__global__ __launch_bounds__(256) void embed_sum_norm_kernel(EmbedSumArgs a, const float* __restrict__ norm_w, float eps,
+                                                             float* resid_out, T* xn) {
+    __shared__ float red[32];
+    const int b = blockIdx.x;
+    const int step = *a.step;
+    const unsigned* codes = a.codes_base + (long)b * a.row_stride + (long)step * a.G;
+    const float* add = step < a.trailing_len[b] ? a.trailing + ((long)b * a.Tt_max + step) * a.H : a.tts_pad;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < a.H; i += blockDim.x) {
+        float v = to_f32<TE>(((const TE*)a.codec_emb)[(long)codes[0] * a.H + i]);
+        for (int g = 1; g < a.G; ++g) v = v + to_f32<TE>(((const TE*)a.cp_emb[g - 1])[(long)codes[g] * a.H + i]);
+        v = v + add[i];
+        resid_out[(long)b * a.H + i] = v;
+        ss += v * v;
+    }
+    rmsnorm_tail<T>(resid_out + (long)b * a.H, ss, norm_w, eps, xn + (long)b * a.H, nullptr, a.H, red);
+}
+
+void launch_embed_sum_norm(hipStream_t st, int dtype, const EmbedSumArgs& a, const float* norm_w, float eps, float* resid_out,
+                           void* xn) {
+    QTTS_CHECK(a.B >= 1 && a.H % 4 == 0, ERR_SHAPE, "embed_sum: bad shape");
+    if (a.edtype == BF16 && dtype == BF16) hipLaunchKernelGGL((embed_sum_norm_kernel<bf16_t, bf16_t>), dim3(a.B), dim3(256), 0, st, a, norm_w, eps, resid_out, (bf16_t*)xn);
+    else if (a.edtype == F32 && dtype == F32) hipLaunchKernelGGL((embed_sum_norm_kernel<float, float>), dim3(a.B), dim3(256), 0, st, a, norm_w, eps, resid_out, (float*)xn);
+    else throw Error(ERR_BAD_ARG, "embed_sum: embedding and activation dtypes must match");
+}
+
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void gather_codes_kernel(const TS* __restrict__ table, const unsigned* codes_base,
+                                                           long row_stride, const int* step, int G, int g, TD* dst, int H) {
+    const int b = blockIdx.x;
+    const unsigned code = codes_base[(long)b * row_stride + (long)(*step) * G + g];
+    const TS* src = table + (long)code * H;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) dst[(long)b * H + i] = from_f32<TD>(to_f32<TS>(src[i]));
+}
+
+void launch_gather_codes(hipStream_t st, const void* table, int tdtype, const unsigned* codes_base, long row_stride,
+                         const int* step, int G, int g, void* dst, int ddtype, int B, int H) {
+    dim3 gr(B), bl(256);
+    if (tdtype == BF16 && ddtype == BF16) hipLaunchKernelGGL((gather_codes_kernel<bf16_t, bf16_t>), gr, bl, 0, st, (const bf16_t*)table, codes_base, row_stride, step, G, g, (bf16_t*)dst, H);
+    else if (tdtype == F32 && ddtype == F32) hipLaunchKernelGGL((gather_codes_kernel<float, float>), gr, bl, 0, st, (const float*)table, codes_base, row_stride, step, G, g, (float*)dst, H);
+    else if (tdtype == BF16) hipLaunchKernelGGL((gather_codes_kernel<bf16_t, float>), gr, bl, 0, st, (const bf16_t*)table, codes_base, row_stride, step, G, g, (float*)dst, H);
+    else hipLaunchKernelGGL((gather_codes_kernel<float, bf16_t>), gr, bl, 0, st, (const float*)table, codes_base, row_stride, step, G, g, (bf16_t*)dst, H);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict__ src, T* dst, long n) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long)gridDim.x * blockDim.x) dst[e] = from_f32<T>(src[e]);
+}
+void launch_cast_rows(hipStream_t st, const float* src, void* dst, int ddtype, long n) {
+    const int blocks = (int)std::min<long>((n + 255) / 256, 2048);
+    if (ddtype == BF16) hipLaunchKernelGGL(cast_rows_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, src, (bf16_t*)dst, n);
+    else hipLaunchKernelGGL(cast_rows_kernel<float>, dim3(blocks), dim3(256), 0, st, src, (float*)dst, n);
+}
+
+// dst[dst_idx[i]][:] = src[src_idx[i]][:]   (same element type; used to pick each row's last prompt position)
+template <typename T>
+__global__ __launch_bounds__(256) void copy_rows_kernel(const T* __restrict__ src, const int* __restrict__ sidx, T* dst,
+                                                        const int* __restrict__ didx, int H) {
+    const long s = sidx[blockIdx.x], d = didx[blockIdx.x];
+    for (int i = threadIdx.x; i < H; i += blockDim.x) dst[d * H + i] = src[s * H + i];
+}
+void launch_copy_rows(hipStream_t st, const void* src, const int* sidx, void* dst, const int* didx, int dtype, int n, int H) {
+    QTTS_CHECK(n >= 1, ERR_SHAPE, "copy_rows: empty");
+    if (dtype == BF16) hipLaunchKernelGGL(copy_rows_kernel<bf16_t>, dim3(n), dim3(256), 0, st, (const bf16_t*)src, sidx, (bf16_t*)dst, didx, H);
+    else hipLaunchKernelGGL(copy_rows_kernel<float>, dim3(n), dim3(256), 0, st, (const float*)src, sidx, (float*)dst, didx, H);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void make_decode_toks_kernel(int* row_len, Tok* toks, int B, int window) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int pos = row_len[b];
+    row_len[b] = pos + 1;  // the token decoded this step occupies `pos`
+    Tok t;
+    t.row = b;
+    t.pos = pos;
+    t.ctx_start = window > 0 ? max(0, pos + 1 - window) : 0;
+    t.ctx_len = pos + 1 - t.ctx_start;
+    toks[b] = t;
+}
+void launch_make_decode_toks(hipStream_t st, int* row_len, Tok* toks, int B, int window) {
+    hipLaunchKernelGGL(make_decode_toks_kernel, dim3((B + 63) / 64), dim3(64), 0, st, row_len, toks, B, window);
+}
+
+__global__ void advance_step_kernel(int* step) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1;
+}
+void launch_advance_step(hipStream_t st, int* step) { hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, st, step); }
+
+}  // namespace qtts

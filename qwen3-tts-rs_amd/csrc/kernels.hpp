@@ -1,0 +1,115 @@
+// Launchers of the gfx950 kernels.  Every launcher validates the shapes its kernel and grid assume
+// before launching (an out-of-bounds access on this hardware can reset the whole node).
+#pragma once
+#include "common.hpp"
+
+namespace qtts {
+
+// One token in flight: which KV-cache row it belongs to, its position (RoPE + cache slot) and the
+// key range [ctx_start, ctx_start + ctx_len) it attends to.
+struct Tok {
+    int row, pos, ctx_start, ctx_len;
+};
+
+// Paged KV cache of one transformer stack.  A page holds `page_tokens` positions of every kv head of
+// one layer: [layer][page][k|v][kv_head][slot][d].  page_table[row * max_pages + i] = physical page.
+struct KVView {
+    void* base;
+    size_t layer_stride;  // elements
+    int page_tokens, nkv, d, max_pages;
+    const int* page_table;
+};
+
+// ---- k_gemm.hip
+int gemm_pad_rows(int M);
+int gemm_pick_ks(int M, int N, int K, int dtype);
+// out is [KS][gemm_pad_rows(M)][N] f32 partial sums; X has gemm_pad_rows(M) readable rows of ldx elements.
+void launch_gemm(hipStream_t st, int dtype, const void* W, const void* X, float* out, int M, int N, int K, int KS, int ldx);
+
+// ---- k_elem.hip
+// x = [resid] + sum_ks part[ks] + [bias]; resid_out = x (f32, may alias resid); xn = rmsnorm(x) * w -> dtype;
+// xn_f32 (optional) receives the same normalised row in f32.
+void launch_resid_norm(hipStream_t st, int dtype, const float* resid, const float* part, int KS, long ks_stride,
+                       const float* bias, const float* norm_w, float eps, float* resid_out, void* xn, float* xn_f32,
+                       int M, int H);
+// act = silu(sum part[..][0:I]) * sum part[..][I:2I] -> dtype   (candle_nn::ops::swiglu)
+void launch_swiglu(hipStream_t st, int dtype, const float* part, int KS, long ks_stride, void* act, int M, int I);
+// out = act(sum_ks part + bias): act 0 none, 1 silu; out_dtype F32/BF16 independent of the weight dtype
+void launch_bias_act(hipStream_t st, const float* part, int KS, long ks_stride, const float* bias, int act, void* out,
+                     int out_dtype, int M, int N);
+// dst[i][:] = table[idx[i]][:]  (table in `tdtype`, dst in `ddtype`)
+void launch_gather_rows(hipStream_t st, const void* table, int tdtype, const int* idx, void* dst, int ddtype, int M, int H,
+                        long dst_ld);
+// prompt row = text_rows[text_idx] + codec_emb[codec_id] + extra[extra_idx]  (each optional: index < 0 skips)
+void launch_assemble(hipStream_t st, const float* text_rows, const int* text_idx, const void* codec_emb, int edtype,
+                     const int* codec_id, const float* extra, const int* extra_idx, float* out, int M, int H);
+// next talker input: codec_emb[c0] + sum_g cp_emb[g-1][c_g] + (step < Tt ? trailing[step] : tts_pad), then the
+// layer-0 input RMSNorm.  codes points at this step's [B][G] u32 block through (codes_base + *step * step_stride).
+struct EmbedSumArgs {
+    const void* codec_emb;          // [V][H]
+    const void* const* cp_emb;      // device array of G-1 table pointers, each [Vc][H]
+    int edtype;
+    const unsigned* codes_base;     // [B][max_steps][G]
+    long row_stride;                // max_steps * G
+    const int* step;                // device scalar: current frame index
+    const float* trailing;          // [B][Tt_max][H] f32
+    const int* trailing_len;        // [B]
+    int Tt_max;
+    const float* tts_pad;           // [H] f32
+    int G, H, B;
+};
+void launch_embed_sum_norm(hipStream_t st, int dtype, const EmbedSumArgs& a, const float* norm_w, float eps, float* resid_out,
+                           void* xn);
+// code-predictor input rows: dst[b] = table[codes[b][g]] cast to dtype (codes laid out as in EmbedSumArgs)
+void launch_gather_codes(hipStream_t st, const void* table, int tdtype, const unsigned* codes_base, long row_stride,
+                         const int* step, int G, int g, void* dst, int ddtype, int B, int H);
+void launch_cast_rows(hipStream_t st, const float* src, void* dst, int ddtype, long n);
+// decode-step bookkeeping (device-side so the frame can live in a hipGraph)
+// toks[b] = {b, row_len[b], window start, ctx}; row_len[b] += 1
+void launch_make_decode_toks(hipStream_t st, int* row_len, Tok* toks, int B, int window);
+void launch_advance_step(hipStream_t st, int* step);
+void launch_copy_rows(hipStream_t st, const void* src, const int* sidx, void* dst, const int* didx, int dtype, int n, int H);
+
+// ---- k_attn.hip
+struct QkvPostArgs {
+    const float* part;   // [KS][Mpad][(nh + 2 nkv) d]
+    int KS;
+    long ks_stride;
+    const float* bias;   // optional [(nh + 2 nkv) d]
+    const float* q_norm; // [d] or null (no per-head norm)
+    const float* k_norm;
+    float eps;
+    const float* cos;    // [max_pos][d/2]
+    const float* sin;
+    int rope_mode;       // 0: candle rope (pair i, i+d/2 with half-dim tables)
+    const Tok* toks;
+    int M, nh, nkv, d, layer;
+    float* q_out;        // [Mpad][nh d] f32
+};
+void launch_qkv_post(hipStream_t st, int dtype, const QkvPostArgs& a, const KVView& kv);
+// softmax(q k^T * scale over the token's key range) v  -> out [Mpad][nh d] in dtype
+void launch_attention(hipStream_t st, int dtype, const float* q, const Tok* toks, const KVView& kv, int layer, int M, int nh,
+                      float scale, void* out);
+
+// ---- k_sample.hip
+struct SampleArgs {
+    const float* logits;    // [B][V]
+    int V, B;
+    float temperature;      // 1/T applied as a multiply
+    int top_k;
+    float top_p;
+    int do_sample;
+    float rep_penalty;      // 1.0 disables
+    int* hist_count;        // [B][V] occurrences so far (null when rep_penalty == 1)
+    int suppress_lo, suppress_hi, eos_id;  // eos_id < 0: none
+    int min_new_tokens;
+    const int* step;        // device scalar: frame index (== history length)
+    const float* uniforms;  // [B][max_steps][G]
+    unsigned* codes_base;   // [B][max_steps][G]
+    long row_stride;
+    int G, g;               // which codebook column this draw fills
+    int* eos_step;          // [B], -1 until the row's first EOS (only for g == 0)
+};
+void launch_sample(hipStream_t st, const SampleArgs& a);
+
+}  // namespace qtts

@@ -1,0 +1,464 @@
+"""Host-side mirror of the reference's public model API over the libqtts_hip C ABI.
+
+Names, argument meaning and error behaviour follow the `qwen_tts` crate:
+ModelLoader / LoaderConfig (qwen_tts/src/model/loader.rs:31-54,109-118,267), Model and its
+generate_* methods (model/generate.rs:227,343,452,809), GenerateConfig::merge (model/config.rs:128-157),
+GenerationResult (model/types.rs:53-69), decode_output (model/generate.rs:29-143).
+All arithmetic happens in the HIP library; this module only marshals buffers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from dataclasses import dataclass, field
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import QTTS_BF16, QTTS_F32, QttsError, check
+
+
+@dataclass
+class GenerateConfig:  # model/config.rs:9-47
+    do_sample: bool = True
+    top_k: int = 50
+    top_p: float = 1.0
+    temperature: float = 0.9
+    repetition_penalty: float = 1.05
+    subtalker_do_sample: bool = True
+    subtalker_top_k: int = 50
+    subtalker_top_p: float = 1.0
+    subtalker_temperature: float = 0.9
+    max_new_tokens: int = 2048
+
+    @classmethod
+    def from_json(cls, text: str) -> "GenerateConfig":  # model/config.rs:51-87 (note the key `subtalker_dosample`)
+        raw = json.loads(text)
+        d = cls()
+        for k in ("do_sample", "top_k", "top_p", "temperature", "repetition_penalty", "subtalker_top_k",
+                  "subtalker_top_p", "subtalker_temperature", "max_new_tokens"):
+            if raw.get(k) is not None:
+                setattr(d, k, raw[k])
+        if raw.get("subtalker_dosample") is not None:
+            d.subtalker_do_sample = raw["subtalker_dosample"]
+        return d
+
+    def merge(self, **user) -> "SamplingConfig":  # model/config.rs:128-157
+        def pick(k):
+            v = user.get(k)
+            return getattr(self, k) if v is None else v
+        return SamplingConfig(do_sample=pick("do_sample"), top_k=pick("top_k"), top_p=pick("top_p"),
+                              temperature=pick("temperature"), repetition_penalty=pick("repetition_penalty"),
+                              subtalker_do_sample=pick("subtalker_do_sample"), subtalker_top_k=pick("subtalker_top_k"),
+                              subtalker_top_p=pick("subtalker_top_p"),
+                              subtalker_temperature=pick("subtalker_temperature"))
+
+    def effective_max_tokens(self, user_max: Optional[int]) -> int:
+        return self.max_new_tokens if user_max is None else user_max
+
+
+@dataclass
+class SamplingConfig:  # nn/sampling.rs:13-64 (suppress list / eos / min_new_tokens are set inside generate)
+    temperature: float = 0.9
+    top_k: int = 50
+    top_p: float = 1.0
+    do_sample: bool = True
+    repetition_penalty: float = 1.05
+    subtalker_do_sample: bool = True
+    subtalker_temperature: float = 0.9
+    subtalker_top_k: int = 50
+    subtalker_top_p: float = 1.0
+
+    @classmethod
+    def cli_greedy(cls) -> "SamplingConfig":
+        """`qwen-tts --greedy`: do_sample=false for both stages, temperature 1.0; repetition penalty and top-k keep
+        their defaults (synthesis/synthesize_voice.rs:30-38)."""
+        return cls(do_sample=False, subtalker_do_sample=False, temperature=1.0)
+
+    def as_dict(self):
+        return dict(self.__dict__)
+
+    def to_c(self) -> _lib.Sampling:
+        return _lib.Sampling(self.temperature, self.top_k, self.top_p, int(self.do_sample), self.repetition_penalty,
+                             int(self.subtalker_do_sample), self.subtalker_temperature, self.subtalker_top_k,
+                             self.subtalker_top_p)
+
+
+@dataclass
+class GenerationRequest:  # GenerationOptions (nn/generation_options.rs) + text ids
+    text_ids: Sequence[int]
+    language: str = "auto"
+    speaker: Optional[str] = None
+    instruct_ids: Optional[Sequence[int]] = None
+    speaker_embed: Optional[np.ndarray] = None
+    ref_codes: Optional[np.ndarray] = None
+    ref_text_ids: Optional[Sequence[int]] = None
+    non_streaming_mode: bool = True
+    seed: Optional[int] = None
+
+
+@dataclass
+class Output:  # nn/generation.rs:31-38
+    codes: np.ndarray            # (batch, num_steps, groups) u32
+    num_steps: int
+    effective_lengths: list
+
+
+@dataclass
+class GenerationResult:  # model/types.rs:53-69
+    audio: list                  # per-sample float32 waveforms
+    sample_rate: int
+    codes: Optional[np.ndarray] = None
+    effective_lengths: Optional[list] = None
+
+
+@dataclass
+class LoaderConfig:  # model/loader.rs:31-54
+    dtype: str = "bf16"
+    load_tokenizer: bool = True
+    device: int = 0
+
+
+class Model:
+    """ConditionalGeneration + TokenizerV2 behind one handle (model/mod.rs:128-140)."""
+
+    def __init__(self, config: dict, codec_config: Optional[dict], loader: LoaderConfig = LoaderConfig(),
+                 generate_defaults: Optional[GenerateConfig] = None):
+        self.lib = _lib.load()
+        self.config = config
+        self.codec_config = codec_config
+        self.generate_defaults = generate_defaults or GenerateConfig()
+        self.dtype = QTTS_BF16 if loader.dtype in ("bf16", "bfloat16") else QTTS_F32
+        self._ctx = C.c_void_p()
+        check(self.lib.qtts_init(loader.device, C.byref(self._ctx)))
+        self._m = C.c_void_p()
+        cj = json.dumps(codec_config).encode() if codec_config is not None else None
+        check(self.lib.qtts_model_create(self._ctx, json.dumps(config).encode(), cj, self.dtype, C.byref(self._m)))
+        self._finalized = False
+        self.last_timing = None
+
+    def close(self):
+        if getattr(self, "_m", None) is not None and self._m:
+            self.lib.qtts_model_free(self._m)
+            self._m = C.c_void_p()
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self.lib.qtts_shutdown(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ loading
+    def load_tensor(self, key: str, arr):
+        """Host numpy array (f32, or uint16 holding bf16 bits) or a CUDA torch tensor (f32 / bf16)."""
+        if hasattr(arr, "is_cuda") and arr.is_cuda:
+            import torch
+            t = arr.contiguous()
+            src = QTTS_BF16 if t.dtype == torch.bfloat16 else QTTS_F32
+            if t.dtype not in (torch.bfloat16, torch.float32):
+                raise QttsError(-1, "device tensors must be f32 or bf16")
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            check(self.lib.qtts_model_load_tensor_device(self._m, key.encode(), C.c_void_p(t.data_ptr()), src, shape, t.dim()))
+            return
+        a = np.ascontiguousarray(arr)
+        if a.dtype == np.uint16:
+            src = QTTS_BF16
+        else:
+            a = np.ascontiguousarray(a, np.float32)
+            src = QTTS_F32
+        shape = (C.c_int64 * a.ndim)(*a.shape)
+        check(self.lib.qtts_model_load_tensor(self._m, key.encode(), a.ctypes.data_as(C.c_void_p), src, shape, a.ndim))
+
+    def load_weights(self, items: Iterable):
+        for k, a in items:
+            self.load_tensor(k, a)
+
+    def finalize(self):
+        check(self.lib.qtts_model_finalize(self._m))
+        self._finalized = True
+        return self
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def hidden_size(self):
+        return self.config["talker_config"]["hidden_size"]
+
+    @property
+    def num_code_groups(self):
+        return self.config["talker_config"]["num_code_groups"]
+
+    def sample_rate(self) -> int:  # model/generate.rs:196-201
+        return (self.codec_config or {}).get("output_sample_rate", 24000)
+
+    def total_upsample(self) -> int:
+        d = self.codec_config["decoder_config"]
+        return int(np.prod(d["upsample_rates"]) * np.prod(d["upsampling_ratios"]))
+
+    # ------------------------------------------------------------------ validation (model/mod.rs:341-419)
+    def model_type(self) -> str:
+        return (self.config.get("tts_model_type") or "").lower()
+
+    def validate_speaker(self, speaker: str):
+        ids = self.config["talker_config"].get("spk_id") or {}
+        if speaker.lower() not in ids:
+            raise QttsError(-1, f"Unknown speaker '{speaker}'. Available: {sorted(ids)}")
+
+    def validate_language(self, language: str):
+        ids = self.config["talker_config"].get("codec_language_id") or {}
+        if language.lower() != "auto" and language.lower() not in ids:
+            raise QttsError(-1, f"Unsupported language '{language}'. Available: {['auto'] + sorted(ids)}")
+
+    # ------------------------------------------------------------------ generation
+    def generate(self, requests: Sequence[GenerationRequest], sampling: SamplingConfig, max_new_tokens: int,
+                 trace: bool = False, use_graph: bool = True, profile_gemm: bool = False) -> Output:
+        """ConditionalGeneration::generate (nn/generation.rs:815) over a batch of independent utterances."""
+        n = len(requests)
+        G = self.num_code_groups
+        V = self.config["talker_config"]["vocab_size"]
+        H = self.hidden_size
+        reqs = (_lib.Request * n)()
+        keep = []
+        for i, r in enumerate(requests):
+            t = np.ascontiguousarray(r.text_ids, np.uint32)
+            keep.append(t)
+            reqs[i].text_ids = t.ctypes.data_as(C.POINTER(C.c_uint32))
+            reqs[i].n_text = len(t)
+            if r.instruct_ids is not None and len(r.instruct_ids):
+                ins = np.ascontiguousarray(r.instruct_ids, np.uint32)
+                keep.append(ins)
+                reqs[i].instruct_ids = ins.ctypes.data_as(C.POINTER(C.c_uint32))
+                reqs[i].n_instruct = len(ins)
+            reqs[i].language = (r.language or "auto").encode()
+            reqs[i].speaker = r.speaker.encode() if r.speaker else None
+            if r.speaker_embed is not None:
+                se = np.ascontiguousarray(r.speaker_embed, np.float32).reshape(-1)
+                if se.size != H:
+                    raise QttsError(-4, "speaker_embed must have hidden_size elements")
+                keep.append(se)
+                reqs[i].speaker_embed = se.ctypes.data_as(C.POINTER(C.c_float))
+            if r.ref_codes is not None:
+                rc = np.ascontiguousarray(r.ref_codes, np.uint32)
+                keep.append(rc)
+                reqs[i].ref_codes = rc.ctypes.data_as(C.POINTER(C.c_uint32))
+                reqs[i].ref_T = rc.shape[0]
+            if r.ref_text_ids is not None:
+                rt = np.ascontiguousarray(r.ref_text_ids, np.uint32)
+                keep.append(rt)
+                reqs[i].ref_text_ids = rt.ctypes.data_as(C.POINTER(C.c_uint32))
+                reqs[i].n_ref_text = len(rt)
+            reqs[i].non_streaming = int(r.non_streaming_mode)
+            reqs[i].use_seed = 0 if r.seed is None else 1
+            reqs[i].seed = 0 if r.seed is None else int(r.seed)
+        codes = np.zeros((n, max_new_tokens, G), np.uint32)
+        outs = (_lib.CodesOut * n)()
+        for i in range(n):
+            outs[i].codes = codes[i].ctypes.data_as(C.POINTER(C.c_uint32))
+        sc = sampling.to_c()
+        dbg = _lib.GenDebug()
+        logits = hidden = None
+        if trace:
+            logits = np.zeros((n, max_new_tokens, V), np.float32)
+            hidden = np.zeros((n, max_new_tokens, H), np.float32)
+            dbg.logits = logits.ctypes.data_as(C.POINTER(C.c_float))
+            dbg.hidden = hidden.ctypes.data_as(C.POINTER(C.c_float))
+        dbg.use_graph = int(use_graph)
+        dbg.profile_gemm = int(profile_gemm)
+        check(self.lib.qtts_generate_ex(self._m, reqs, n, C.byref(sc), max_new_tokens, outs, C.byref(dbg)))
+        tm = (C.c_double * 8)()
+        check(self.lib.qtts_last_timing(self._m, tm, 8))
+        self.last_timing = dict(prefill_ms=tm[0], frames_ms=tm[1], gemm_ms=tm[2], gemm_launches=int(tm[3]),
+                                gemm_bytes=tm[4], frames=int(tm[5]))
+        steps = outs[0].num_steps
+        out = Output(codes=codes[:, :steps].copy(), num_steps=steps, effective_lengths=[outs[i].effective_len for i in range(n)])
+        if trace:
+            out.logits = logits[:, :steps]
+            out.hidden = hidden[:, :steps]
+        return out
+
+    def decode_codes(self, codes: np.ndarray, lens: Optional[Sequence[int]] = None, chunk: int = 0, left_ctx: int = 0):
+        """TokenizerV2::decode / chunked_decode on (batch, steps, quantizers) codes; returns a list of waveforms."""
+        c = np.ascontiguousarray(codes, np.uint32)
+        if c.ndim == 2:
+            c = c[None]
+        B, T, Q = c.shape
+        lens_a = np.ascontiguousarray(lens if lens is not None else [T] * B, np.int32)
+        stride = (T + 1) * self.total_upsample()
+        wav = np.zeros((B, stride), np.float32)
+        wl = np.zeros(B, np.int64)
+        check(self.lib.qtts_codec_decode(self._m, c.ctypes.data_as(C.c_void_p), lens_a.ctypes.data_as(C.c_void_p), B, T, chunk,
+                                         left_ctx, wav.ctypes.data_as(C.c_void_p), stride, wl.ctypes.data_as(C.c_void_p)))
+        return [wav[b, :wl[b]].copy() for b in range(B)]
+
+    def decode_output(self, output: Output):
+        """Model::decode_output (model/generate.rs:29-143): truncate to effective lengths, chunk long sequences."""
+        return self.decode_codes(output.codes, output.effective_lengths, chunk=-2, left_ctx=0)
+
+    def compute_mel_spectrogram(self, audio: Sequence[np.ndarray]):
+        """Model::compute_mel_spectrogram (model/mod.rs:520-528): list of (frames, 128) arrays."""
+        B = len(audio)
+        ns = np.array([len(a) for a in audio], np.int32)
+        mx = int(ns.max())
+        buf = np.zeros((B, mx), np.float32)
+        for b, a in enumerate(audio):
+            buf[b, :len(a)] = a
+        fs = mx // 256 + 8
+        mel = np.zeros((B, fs, 128), np.float32)
+        nf = np.zeros(B, np.int32)
+        check(self.lib.qtts_mel(self._m, buf.ctypes.data_as(C.c_void_p), ns.ctypes.data_as(C.c_void_p), B, mx,
+                                mel.ctypes.data_as(C.c_void_p), fs, nf.ctypes.data_as(C.c_void_p)))
+        return [mel[b, :nf[b]].copy() for b in range(B)]
+
+    def extract_speaker_embedding(self, audio: Sequence[np.ndarray]) -> np.ndarray:
+        """mel + ConditionalGeneration::encode_speaker (model/mod.rs:560-600): (batch, enc_dim)."""
+        s = self.config.get("speaker_encoder_config")
+        if not s:
+            raise QttsError(-5, "Speaker encoder not available - this model doesn't support voice cloning. "
+                                "Use a Base model for voice cloning.")
+        B = len(audio)
+        ns = np.array([len(a) for a in audio], np.int32)
+        mx = int(ns.max())
+        buf = np.zeros((B, mx), np.float32)
+        for b, a in enumerate(audio):
+            buf[b, :len(a)] = a
+        emb = np.zeros((B, s["enc_dim"]), np.float32)
+        check(self.lib.qtts_speaker_embed(self._m, buf.ctypes.data_as(C.c_void_p), ns.ctypes.data_as(C.c_void_p), B, mx,
+                                          emb.ctypes.data_as(C.c_void_p)))
+        return emb
+
+    # ---- high-level API (model/generate.rs:227-848); text arrives tokenised (the tokenizer stays on the host side)
+    def _finish(self, out: Output, decode: bool) -> GenerationResult:
+        if out.num_steps == 0:
+            raise QttsError(-5, "Generation produced no audio. The model generated 0 steps.")
+        audio = self.decode_output(out) if decode and self.codec_config is not None else []
+        return GenerationResult(audio=audio, sample_rate=self.sample_rate(), codes=out.codes,
+                                effective_lengths=out.effective_lengths)
+
+    def generate_custom_voice_full(self, text_ids, speaker: str, language: str, instruct_ids=None, options: dict = None,
+                                   decode: bool = True) -> GenerationResult:
+        if self.model_type() not in ("custom_voice", "customvoice", ""):
+            raise QttsError(-5, f"Model type '{self.model_type()}' does not support custom voice generation")
+        self.validate_speaker(speaker)
+        self.validate_language(language)
+        o = dict(options or {})
+        sampling = self.generate_defaults.merge(**o)
+        mx = self.generate_defaults.effective_max_tokens(o.get("max_new_tokens"))
+        req = GenerationRequest(text_ids=text_ids, language=language, speaker=speaker, instruct_ids=instruct_ids,
+                                non_streaming_mode=o.get("non_streaming_mode", True) is not False, seed=o.get("seed"))
+        return self._finish(self.generate([req], sampling, mx), decode)
+
+    def generate_voice_design_full(self, text_ids, instruct_ids, language: str, options: dict = None,
+                                   decode: bool = True) -> GenerationResult:
+        self.validate_language(language)
+        o = dict(options or {})
+        sampling = self.generate_defaults.merge(**o)
+        mx = self.generate_defaults.effective_max_tokens(o.get("max_new_tokens"))
+        req = GenerationRequest(text_ids=text_ids, language=language, instruct_ids=instruct_ids,
+                                non_streaming_mode=o.get("non_streaming_mode", True) is not False, seed=o.get("seed"))
+        return self._finish(self.generate([req], sampling, mx), decode)
+
+    def generate_voice_clone_full(self, text_ids, language: str, speaker_embed: np.ndarray, options: dict = None,
+                                  decode: bool = True) -> GenerationResult:
+        """x-vector-only voice clone (model/generate.rs:452-530): the speaker embedding takes one prompt position."""
+        self.validate_language(language)
+        o = dict(options or {})
+        sampling = self.generate_defaults.merge(**o)
+        mx = self.generate_defaults.effective_max_tokens(o.get("max_new_tokens"))
+        req = GenerationRequest(text_ids=text_ids, language=language, speaker_embed=speaker_embed,
+                                non_streaming_mode=o.get("non_streaming_mode", True) is not False, seed=o.get("seed"))
+        return self._finish(self.generate([req], sampling, mx), decode)
+
+    def generate_custom_voice_from_texts_batch(self, text_ids_list, speaker: str, language: str, options: dict = None,
+                                               decode: bool = True) -> GenerationResult:
+        """model/generate.rs:809-848 loops utterance by utterance; here the rows share one batched decode."""
+        self.validate_speaker(speaker)
+        self.validate_language(language)
+        o = dict(options or {})
+        sampling = self.generate_defaults.merge(**o)
+        mx = self.generate_defaults.effective_max_tokens(o.get("max_new_tokens"))
+        seed = o.get("seed")
+        reqs = [GenerationRequest(text_ids=t, language=language, speaker=speaker,
+                                  seed=None if seed is None else seed + i) for i, t in enumerate(text_ids_list)]
+        return self._finish(self.generate(reqs, sampling, mx), decode)
+
+
+class ModelLoader:
+    """ModelLoader (model/loader.rs:109-118): reads config.json, speech_tokenizer/config.json,
+    generate_config.json and the safetensors files of a model directory."""
+
+    def __init__(self, model_dir: str):
+        self.model_dir = model_dir
+        with open(os.path.join(model_dir, "config.json")) as f:
+            self.config = json.load(f)
+        cpath = os.path.join(model_dir, "speech_tokenizer", "config.json")
+        self.codec_config = json.load(open(cpath)) if os.path.exists(cpath) else None
+        gpath = os.path.join(model_dir, "generate_config.json")
+        self.generate_defaults = GenerateConfig.from_json(open(gpath).read()) if os.path.exists(gpath) else GenerateConfig()
+
+    @classmethod
+    def from_local_dir(cls, model_dir: str) -> "ModelLoader":
+        if not os.path.exists(os.path.join(model_dir, "config.json")):
+            raise FileNotFoundError(f"config.json not found in {model_dir}")
+        return cls(model_dir)
+
+    def _tensor_files(self):
+        # like the reference, only the first shard of a sharded checkpoint is opened (model/loader.rs:219-235)
+        main = os.path.join(self.model_dir, "model.safetensors")
+        if not os.path.exists(main):
+            shards = sorted(f for f in os.listdir(self.model_dir) if f.startswith("model-") and f.endswith(".safetensors"))
+            if not shards:
+                raise FileNotFoundError("no model.safetensors in " + self.model_dir)
+            main = os.path.join(self.model_dir, shards[0])
+        files = [main]
+        tok = os.path.join(self.model_dir, "speech_tokenizer", "model.safetensors")
+        if os.path.exists(tok):
+            files.append(tok)
+        return files
+
+    def load_tts_model(self, loader: LoaderConfig = LoaderConfig()) -> Model:
+        from safetensors import safe_open
+        m = Model(self.config, self.codec_config if loader.load_tokenizer else None, loader, self.generate_defaults)
+        for path in self._tensor_files():
+            with safe_open(path, framework="np") as f:
+                for key in f.keys():
+                    if key.startswith("encoder."):
+                        continue  # codec encoder weights are not part of this path
+                    try:
+                        arr = f.get_tensor(key)
+                    except TypeError:  # bf16 is not a numpy dtype: read the raw bits through torch
+                        import torch
+                        from safetensors import safe_open as so
+                        with so(path, framework="pt") as ft:
+                            arr = ft.get_tensor(key).view(torch.uint16).numpy()
+                    m.load_tensor(key, arr)
+        return m.finalize()
+
+
+def synthetic_model(shape: str, dtype: str = "bf16", seed: int = 20261111, model_type: str = "custom_voice", codec: bool = True,
+                    talker: bool = True, device: int = 0, round_to_bf16: bool = False):
+    """Random-init model of a named shape set (see synth.py).  Returns (Model, config, codec_config, template)."""
+    from . import synth
+    cfg, ccfg, tmpl = synth.shape_set(shape, model_type)
+    m = Model(cfg, ccfg if codec else None, LoaderConfig(dtype=dtype, device=device))
+    keys = []
+    if talker:
+        keys += synth.talker_keys(cfg) + synth.speaker_keys(cfg)
+    if codec:
+        keys += synth.codec_keys(ccfg)
+    for k, a in synth.iter_weights(keys, seed):
+        if round_to_bf16:
+            a = round_bf16(a)
+        m.load_tensor(k, a)
+    m.finalize()
+    return m, cfg, ccfg, tmpl
+
+
+def round_bf16(a: np.ndarray) -> np.ndarray:
+    """f32 -> nearest-even bf16 -> f32 (so that a bf16 run and its f32 reference share identical weights)."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000))
+    return r.view(np.float32).reshape(a.shape)
