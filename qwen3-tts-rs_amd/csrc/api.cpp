@@ -150,6 +150,64 @@ int qtts_speaker_embed(qtts_model* m, const float* audio, const int* n_samples, 
     QTTS_API_END
 }
 
+// Diagnostics: average duration (microseconds, HIP events) of `iters` back-to-back launches of the weight-streaming
+// GEMM on random-free zero... buffers of the given shape; used by the benchmark to report the kernel's roofline.
+int qtts_bench_gemm(qtts_ctx* ctx, int dtype, int M, int N, int K, int KS, int iters, double* avg_us) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(ctx && avg_us && iters >= 1, ERR_BAD_ARG, "qtts_bench_gemm: bad argument");
+    QTTS_HIP(hipSetDevice(ctx->c.device));
+    const size_t es = dtype_size(dtype);
+    const int Mpad = gemm_pad_rows(M);
+    if (KS <= 0) KS = gemm_pick_ks(M, N, K, dtype);
+    // rotate over several weight copies so that consecutive launches do not hit the Infinity Cache
+    const size_t wbytes = (size_t)N * K * es;
+    const int copies = (int)std::max<size_t>(1, std::min<size_t>(16, ((size_t)600 << 20) / wbytes + 1));
+    DevBuf W, X, out;
+    W.alloc(wbytes * copies);
+    X.alloc((size_t)Mpad * K * es);
+    out.alloc((size_t)KS * Mpad * N * 4);
+    QTTS_HIP(hipMemsetAsync(W.p, 0x3c, wbytes * copies, ctx->c.stream));
+    QTTS_HIP(hipMemsetAsync(X.p, 0x3c, (size_t)Mpad * K * es, ctx->c.stream));
+    hipEvent_t e0, e1;
+    QTTS_HIP(hipEventCreate(&e0));
+    QTTS_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch_gemm(ctx->c.stream, dtype, (char*)W.p + wbytes * (i % copies), X.p, out.as<float>(), M, N, K, KS, K);
+    QTTS_HIP(hipEventRecord(e0, ctx->c.stream));
+    for (int i = 0; i < iters; ++i) launch_gemm(ctx->c.stream, dtype, (char*)W.p + wbytes * (i % copies), X.p, out.as<float>(), M, N, K, KS, K);
+    QTTS_HIP(hipEventRecord(e1, ctx->c.stream));
+    QTTS_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    QTTS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = (double)ms * 1000.0 / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    QTTS_API_END
+}
+
+int qtts_bench_stream(qtts_ctx* ctx, long bytes, int blocks, int pattern, int unroll, int ld_bytes, int iters, double* avg_us) {
+    QTTS_API_BEGIN
+    QTTS_HIP(hipSetDevice(ctx->c.device));
+    const int copies = (int)std::max<long>(1, std::min<long>(16, ((long)600 << 20) / bytes + 1));
+    DevBuf src, sink;
+    src.alloc((size_t)bytes * copies);
+    sink.alloc(64);
+    QTTS_HIP(hipMemsetAsync(src.p, 0x11, (size_t)bytes * copies, ctx->c.stream));
+    hipEvent_t e0, e1;
+    QTTS_HIP(hipEventCreate(&e0));
+    QTTS_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch_stream(ctx->c.stream, (char*)src.p + (size_t)bytes * (i % copies), sink.as<unsigned>(), bytes, blocks, pattern, unroll, ld_bytes);
+    QTTS_HIP(hipEventRecord(e0, ctx->c.stream));
+    for (int i = 0; i < iters; ++i) launch_stream(ctx->c.stream, (char*)src.p + (size_t)bytes * (i % copies), sink.as<unsigned>(), bytes, blocks, pattern, unroll, ld_bytes);
+    QTTS_HIP(hipEventRecord(e1, ctx->c.stream));
+    QTTS_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    QTTS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_us = (double)ms * 1000.0 / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    QTTS_API_END
+}
+
 int qtts_model_info(qtts_model* m, int* hidden, int* vocab, int* groups, int* total_upsample, int* enc_dim) {
     QTTS_API_BEGIN
     QTTS_CHECK(m, ERR_BAD_ARG, "qtts_model_info: null model");

@@ -4,6 +4,7 @@
 // passes (nn/code_predictor.rs:433-531) and the next-input embedding sum.  No host round trip
 // happens inside a frame; the host only polls the per-row EOS steps every few frames.
 #include "generate.hpp"
+#include "runner.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -64,7 +65,7 @@ struct StackRun {
 
 struct GenState {
     // activations (token-major rows)
-    DevBuf x, xn, part, q, attn, act;       // residual f32 | gemm input T | split-K partials f32 | q f32 | attn T | mlp act T
+    Workspace ws;                            // activation scratch shared by every layer
     DevBuf cp_in_t, cp_in_f, hid_scratch_f; // code-predictor inputs; rows [0,B) double as the talker's post-norm hidden
     DevBuf text_rows, extra, trailing, tts_pad_dummy;
     DevBuf ibuf;                             // int scratch: ids / descriptors
@@ -73,87 +74,12 @@ struct GenState {
     DevBuf trace_logits, trace_hidden;
     StackRun talker, cp;
     size_t cap_rows = 0;
-    // GEMM event timing
-    std::vector<hipEvent_t> ev;
-    size_t ev_used = 0;
-    double gemm_bytes = 0;
-    bool profile = false;
+    GemmTimer timer;                         // optional HIP-event timing of every GEMM launch
     hipGraphExec_t graph_exec = nullptr;
     ~GenState() {
-        for (auto e : ev) (void)hipEventDestroy(e);
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     }
 };
-
-namespace {
-
-struct Runner {
-    Model& m;
-    GenState& g;
-    hipStream_t st;
-    int dt;
-    size_t es;
-
-    Runner(Model& model, GenState& gs) : m(model), g(gs), st(model.ctx->stream), dt(model.dtype), es(dtype_size(model.dtype)) {}
-
-    void gemm(const void* W, const void* X, int M, int N, int K, int KS, int ldx) {
-        if (g.profile && g.ev_used + 2 <= 400000) {
-            while (g.ev.size() < g.ev_used + 2) {
-                hipEvent_t e;
-                QTTS_HIP(hipEventCreate(&e));
-                g.ev.push_back(e);
-            }
-            QTTS_HIP(hipEventRecord(g.ev[g.ev_used], st));
-            launch_gemm(st, dt, W, X, g.part.as<float>(), M, N, K, KS, ldx);
-            QTTS_HIP(hipEventRecord(g.ev[g.ev_used + 1], st));
-            g.ev_used += 2;
-            g.gemm_bytes += (double)N * K * es;
-        } else {
-            launch_gemm(st, dt, W, X, g.part.as<float>(), M, N, K, KS, ldx);
-        }
-    }
-    long kstride(int M, int N) const { return (long)gemm_pad_rows(M) * N; }
-
-    // One decoder layer over M tokens (nn/decoder_layer.rs:63-86).  On entry x holds the residual
-    // stream and xn = RMSNorm_ln1(x); on exit xn = RMSNorm_next(x) with `next_norm` the following
-    // layer's input norm (or the stack's final norm).
-    void layer(const StackW& s, int l, int M, const Tok* toks, const KVView& kv, const float* next_norm, void* xn_out,
-               float* xn_f32_out) {
-        const StackCfg& c = s.cfg;
-        const LayerW& w = s.layers[(size_t)l];
-        const int nq = c.nh * c.d, nqkv = (c.nh + 2 * c.nkv) * c.d;
-        int ks = gemm_pick_ks(M, nqkv, c.hidden, dt);
-        gemm(w.qkv, g.xn.p, M, nqkv, c.hidden, ks, c.hidden);
-        QkvPostArgs qa{};
-        qa.part = g.part.as<float>(); qa.KS = ks; qa.ks_stride = kstride(M, nqkv); qa.bias = w.qkv_bias;
-        qa.q_norm = w.q_norm; qa.k_norm = w.k_norm; qa.eps = c.eps; qa.cos = s.cos.as<float>(); qa.sin = s.sin.as<float>();
-        qa.rope_mode = 0; qa.toks = toks; qa.M = M; qa.nh = c.nh; qa.nkv = c.nkv; qa.d = c.d; qa.layer = l;
-        qa.q_out = g.q.as<float>();
-        launch_qkv_post(st, dt, qa, kv);
-        launch_attention(st, dt, g.q.as<float>(), toks, kv, l, M, c.nh, (float)std::pow((double)c.d, -0.5), g.attn.p);
-        ks = gemm_pick_ks(M, c.hidden, nq, dt);
-        gemm(w.o, g.attn.p, M, c.hidden, nq, ks, nq);
-        launch_resid_norm(st, dt, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), w.o_bias, w.ln2, c.eps,
-                          g.x.as<float>(), g.xn.p, nullptr, M, c.hidden);
-        ks = gemm_pick_ks(M, 2 * c.inter, c.hidden, dt);
-        gemm(w.gate_up, g.xn.p, M, 2 * c.inter, c.hidden, ks, c.hidden);
-        launch_swiglu(st, dt, g.part.as<float>(), ks, kstride(M, 2 * c.inter), g.act.p, M, c.inter);
-        ks = gemm_pick_ks(M, c.hidden, c.inter, dt);
-        gemm(w.down, g.act.p, M, c.hidden, c.inter, ks, c.inter);
-        launch_resid_norm(st, dt, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), nullptr, next_norm, c.eps,
-                          g.x.as<float>(), xn_out, xn_f32_out, M, c.hidden);
-    }
-
-    void stack(const StackW& s, int M, const Tok* toks, const KVView& kv, void* final_xn, float* final_xn_f32) {
-        for (int l = 0; l < s.cfg.layers; ++l) {
-            const bool last = l + 1 == s.cfg.layers;
-            layer(s, l, M, toks, kv, last ? s.final_norm : s.layers[(size_t)l + 1].ln1, last ? final_xn : g.xn.p,
-                  last ? final_xn_f32 : nullptr);
-        }
-    }
-};
-
-}  // namespace
 
 void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling* sp, int max_new, qtts_codes_out* outs,
                   const qtts_gen_debug* dbg) {
@@ -165,14 +91,14 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     const int B = n, H = c.talker.hidden, Ht = c.text_hidden, G = c.groups, V = c.vocab, Vc = c.cp_vocab, Hc = c.cp.hidden;
     if (!m.gen) m.gen.reset(new GenState());
     GenState& g = *m.gen;
-    Runner R(m, g);
+    Runner R(m, g.ws, &g.timer);
     hipStream_t st = R.st;
     const int dt = m.dtype;
     const size_t es = R.es;
     const bool use_graph = dbg ? dbg->use_graph != 0 : true;
-    g.profile = dbg && dbg->profile_gemm && !use_graph;
-    g.ev_used = 0;
-    g.gemm_bytes = 0;
+    g.timer.enabled = dbg && dbg->profile_gemm && !use_graph;
+    g.timer.used = 0;
+    g.timer.bytes = 0;
 
     // ------------------------------------------------------------------ host-side prompt planning
     std::vector<int> text_ids = {c.tts_bos, c.tts_eos, c.tts_pad};  // rows 0,1,2 of the projected-text buffer
@@ -264,12 +190,12 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     const int Imax = std::max({c.talker.inter, c.cp.inter, Ht, H, Hc});
     const int Nmax = std::max({(c.talker.nh + 2 * c.talker.nkv) * c.talker.d, (c.cp.nh + 2 * c.cp.nkv) * c.cp.d, 2 * c.talker.inter,
                                2 * c.cp.inter, V, Vc, H, Ht, Hc});
-    g.x.ensure(rows * Wmax * 4);
-    g.xn.ensure(rows * Wmax * es);
-    g.part.ensure(rows * (size_t)Nmax * 4 * 16);  // up to 16 split-K slabs
-    g.q.ensure(rows * QD * 4);
-    g.attn.ensure(rows * QD * es);
-    g.act.ensure(rows * Imax * es);
+    g.ws.x.ensure(rows * Wmax * 4);
+    g.ws.xn.ensure(rows * Wmax * es);
+    g.ws.part.ensure(rows * (size_t)Nmax * 4 * 16);  // up to 16 split-K slabs
+    g.ws.q.ensure(rows * QD * 4);
+    g.ws.attn.ensure(rows * QD * es);
+    g.ws.act.ensure(rows * Imax * es);
     const size_t cp_rows = (size_t)gemm_pad_rows(2 * B) + 64;
     g.cp_in_t.ensure(cp_rows * H * es);
     g.cp_in_f.ensure(cp_rows * H * 4);
@@ -382,13 +308,13 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     // ------------------------------------------------------------------ text projection (talker.rs:345-348, mlp.rs:149-160)
     for (int o = 0; o < Nt; o += chunk_rows) {
         const int M = std::min(chunk_rows, Nt - o);
-        launch_gather_rows(st, m.text_emb, dt, d_textids + o, g.xn.p, dt, M, Ht, Ht);
-        int ks = gemm_pick_ks(M, Ht, Ht, dt);
-        R.gemm(m.fc1, g.xn.p, M, Ht, Ht, ks, Ht);
-        launch_bias_act(st, g.part.as<float>(), ks, R.kstride(M, Ht), m.fc1_b, 1, g.act.p, dt, M, Ht);
-        ks = gemm_pick_ks(M, H, Ht, dt);
-        R.gemm(m.fc2, g.act.p, M, H, Ht, ks, Ht);
-        launch_bias_act(st, g.part.as<float>(), ks, R.kstride(M, H), m.fc2_b, 0, g.text_rows.as<float>() + (size_t)o * H, F32, M, H);
+        launch_gather_rows(st, m.text_emb, dt, d_textids + o, g.ws.xn.p, dt, M, Ht, Ht);
+        int ks = R.ks_for(M, Ht, Ht);
+        R.gemm(m.fc1, g.ws.xn.p, M, Ht, Ht, ks, Ht);
+        launch_bias_act(st, g.ws.part.as<float>(), ks, R.kstride(M, Ht), m.fc1_b, 1, g.ws.act.p, dt, M, Ht);
+        ks = R.ks_for(M, H, Ht);
+        R.gemm(m.fc2, g.ws.act.p, M, H, Ht, ks, Ht);
+        launch_bias_act(st, g.ws.part.as<float>(), ks, R.kstride(M, H), m.fc2_b, 0, g.text_rows.as<float>() + (size_t)o * H, F32, M, H);
     }
     launch_gather_rows(st, g.text_rows.p, F32, d_trail, g.trailing.p, F32, B * Tt_max, H, H);
     const float* tts_pad_row = g.text_rows.as<float>() + (size_t)2 * H;
@@ -404,11 +330,11 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         for (int o = 0; o < Ttot; o += chunk_rows) {
             const int M = std::min(chunk_rows, Ttot - o);
             launch_assemble(st, g.text_rows.as<float>(), d_ptext + o, m.codec_emb, dt, d_pcodec + o, g.extra.as<float>(),
-                            d_pextra + o, g.x.as<float>(), M, H);
-            launch_resid_norm(st, dt, g.x.as<float>(), nullptr, 0, 0, nullptr, m.talker.layers[0].ln1, c.talker.eps, g.x.as<float>(),
-                              g.xn.p, nullptr, M, H);
+                            d_pextra + o, g.ws.x.as<float>(), M, H);
+            launch_resid_norm(st, dt, g.ws.x.as<float>(), nullptr, 0, 0, nullptr, nullptr, m.talker.layers[0].ln1, c.talker.eps, g.ws.x.as<float>(),
+                              g.ws.xn.p, nullptr, M, H);
             // final norm output reuses act (T) and q (f32) as scratch rows
-            R.stack(m.talker, M, g.toks_prompt.as<Tok>() + o, g.talker.kv, g.act.p, g.q.as<float>());
+            R.stack(m.talker, M, g.toks_prompt.as<Tok>() + o, g.talker.kv, g.ws.act.p, g.ws.q.as<float>());
             last_src.clear();
             last_dst.clear();
             for (int b = 0; b < B; ++b)
@@ -417,8 +343,8 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
                 const int nl = (int)last_src.size();
                 QTTS_HIP(hipMemcpyAsync(d_last_src, last_src.data(), (size_t)nl * 4, hipMemcpyHostToDevice, st));
                 QTTS_HIP(hipMemcpyAsync(d_last_dst, last_dst.data(), (size_t)nl * 4, hipMemcpyHostToDevice, st));
-                launch_copy_rows(st, g.act.p, d_last_src, hid_t, d_last_dst, dt, nl, H);
-                launch_copy_rows(st, g.q.p, d_last_src, hid_f, d_last_dst, F32, nl, H);
+                launch_copy_rows(st, g.ws.act.p, d_last_src, hid_t, d_last_dst, dt, nl, H);
+                launch_copy_rows(st, g.ws.q.p, d_last_src, hid_f, d_last_dst, F32, nl, H);
                 QTTS_HIP(hipStreamSynchronize(st));  // last_src/last_dst are reused by the next chunk
             }
         }
@@ -457,38 +383,38 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         if (eager_trace && trace_l) {
             // step index is only known on the device; trace copies use the host's mirror of it
         }
-        sample(g.part.as<float>(), V, 0, true);
+        sample(g.ws.part.as<float>(), V, 0, true);
         // ---- code predictor pass 0: [hidden, embed(cb0)] at positions 0, 1
         const Tok* ct = g.toks_cp.as<Tok>();
         if (m.proj) {
             launch_gather_codes(st, m.codec_emb, dt, g.codes.as<unsigned>(), row_stride, d_step, G, 0, (char*)g.cp_in_t.p + (size_t)B * H * es, dt, B, H);
-            const int ks = gemm_pick_ks(2 * B, Hc, H, dt);
+            const int ks = R.ks_for(2 * B, Hc, H);
             R.gemm(m.proj, g.cp_in_t.p, 2 * B, Hc, H, ks, H);
-            launch_resid_norm(st, dt, nullptr, g.part.as<float>(), ks, R.kstride(2 * B, Hc), m.proj_b, m.cp.layers[0].ln1, c.cp.eps,
-                              g.x.as<float>(), g.xn.p, nullptr, 2 * B, Hc);
+            launch_resid_norm(st, dt, nullptr, g.ws.part.as<float>(), ks, R.kstride(2 * B, Hc), m.proj_b, nullptr, m.cp.layers[0].ln1, c.cp.eps,
+                              g.ws.x.as<float>(), g.ws.xn.p, nullptr, 2 * B, Hc);
         } else {
             launch_gather_codes(st, m.codec_emb, dt, g.codes.as<unsigned>(), row_stride, d_step, G, 0, g.cp_in_f.as<float>() + (size_t)B * H, F32, B, H);
-            launch_resid_norm(st, dt, nullptr, g.cp_in_f.as<float>(), 1, 0, nullptr, m.cp.layers[0].ln1, c.cp.eps, g.x.as<float>(),
-                              g.xn.p, nullptr, 2 * B, Hc);
+            launch_resid_norm(st, dt, nullptr, g.cp_in_f.as<float>(), 1, 0, nullptr, nullptr, m.cp.layers[0].ln1, c.cp.eps, g.ws.x.as<float>(),
+                              g.ws.xn.p, nullptr, 2 * B, Hc);
         }
-        R.stack(m.cp, 2 * B, ct, g.cp.kv, g.xn.p, nullptr);
-        R.gemm(m.cp_head[0], (char*)g.xn.p + (size_t)B * Hc * es, B, Vc, Hc, 1, Hc);
-        sample(g.part.as<float>(), Vc, 1, false);
+        R.stack(m.cp, 2 * B, ct, g.cp.kv, g.ws.xn.p, nullptr);
+        R.gemm(m.cp_head[0], (char*)g.ws.xn.p + (size_t)B * Hc * es, B, Vc, Hc, 1, Hc);
+        sample(g.ws.part.as<float>(), Vc, 1, false);
         for (int j = 1; j < G - 1; ++j) {  // code_predictor.rs:480-527
             if (m.proj) {
-                launch_gather_codes(st, m.cp_emb[(size_t)j - 1], dt, g.codes.as<unsigned>(), row_stride, d_step, G, j, g.act.p, dt, B, H);
-                const int ks = gemm_pick_ks(B, Hc, H, dt);
-                R.gemm(m.proj, g.act.p, B, Hc, H, ks, H);
-                launch_resid_norm(st, dt, nullptr, g.part.as<float>(), ks, R.kstride(B, Hc), m.proj_b, m.cp.layers[0].ln1, c.cp.eps,
-                                  g.x.as<float>(), g.xn.p, nullptr, B, Hc);
+                launch_gather_codes(st, m.cp_emb[(size_t)j - 1], dt, g.codes.as<unsigned>(), row_stride, d_step, G, j, g.ws.act.p, dt, B, H);
+                const int ks = R.ks_for(B, Hc, H);
+                R.gemm(m.proj, g.ws.act.p, B, Hc, H, ks, H);
+                launch_resid_norm(st, dt, nullptr, g.ws.part.as<float>(), ks, R.kstride(B, Hc), m.proj_b, nullptr, m.cp.layers[0].ln1, c.cp.eps,
+                                  g.ws.x.as<float>(), g.ws.xn.p, nullptr, B, Hc);
             } else {
-                launch_gather_codes(st, m.cp_emb[(size_t)j - 1], dt, g.codes.as<unsigned>(), row_stride, d_step, G, j, g.q.p, F32, B, H);
-                launch_resid_norm(st, dt, nullptr, g.q.as<float>(), 1, 0, nullptr, m.cp.layers[0].ln1, c.cp.eps, g.x.as<float>(), g.xn.p,
+                launch_gather_codes(st, m.cp_emb[(size_t)j - 1], dt, g.codes.as<unsigned>(), row_stride, d_step, G, j, g.ws.q.p, F32, B, H);
+                launch_resid_norm(st, dt, nullptr, g.ws.q.as<float>(), 1, 0, nullptr, nullptr, m.cp.layers[0].ln1, c.cp.eps, g.ws.x.as<float>(), g.ws.xn.p,
                                   nullptr, B, Hc);
             }
-            R.stack(m.cp, B, ct + 2 * B + (size_t)j * B, g.cp.kv, g.xn.p, nullptr);
-            R.gemm(m.cp_head[(size_t)j], g.xn.p, B, Vc, Hc, 1, Hc);
-            sample(g.part.as<float>(), Vc, j + 1, false);
+            R.stack(m.cp, B, ct + 2 * B + (size_t)j * B, g.cp.kv, g.ws.xn.p, nullptr);
+            R.gemm(m.cp_head[(size_t)j], g.ws.xn.p, B, Vc, Hc, 1, Hc);
+            sample(g.ws.part.as<float>(), Vc, j + 1, false);
         }
         // ---- next talker input (talker.rs:461-479 + generation.rs:1096-1106) and its layer-0 norm
         EmbedSumArgs ea{};
@@ -496,7 +422,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         ea.codes_base = g.codes.as<unsigned>(); ea.row_stride = row_stride; ea.step = d_step;
         ea.trailing = g.trailing.as<float>(); ea.trailing_len = g.trailing_len.as<int>(); ea.Tt_max = Tt_max;
         ea.tts_pad = tts_pad_row; ea.G = G; ea.H = H; ea.B = B;
-        launch_embed_sum_norm(st, dt, ea, m.talker.layers[0].ln1, c.talker.eps, g.x.as<float>(), g.xn.p);
+        launch_embed_sum_norm(st, dt, ea, m.talker.layers[0].ln1, c.talker.eps, g.ws.x.as<float>(), g.ws.xn.p);
         launch_advance_step(st, d_step);
     };
     auto talker_step = [&]() {  // generation.rs:1002-1026
@@ -510,7 +436,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
                                       (size_t)H * 4, B, hipMemcpyDeviceToDevice, st));
         if (trace_l) {
             R.gemm(m.codec_head, hid_t, B, V, H, 1, H);
-            QTTS_HIP(hipMemcpy2DAsync(g.trace_logits.as<float>() + (size_t)step * V, (size_t)max_new * V * 4, g.part.p, (size_t)V * 4,
+            QTTS_HIP(hipMemcpy2DAsync(g.trace_logits.as<float>() + (size_t)step * V, (size_t)max_new * V * 4, g.ws.part.p, (size_t)V * 4,
                                       (size_t)V * 4, B, hipMemcpyDeviceToDevice, st));
         }
     };
@@ -585,15 +511,9 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     QTTS_HIP(hipEventElapsedTime(&ms12, ev1, ev2));
     m.timing[0] = ms01;
     m.timing[1] = ms12;
-    double gemm_ms = 0;
-    for (size_t i = 0; i + 1 < g.ev_used; i += 2) {
-        float t = 0;
-        QTTS_HIP(hipEventElapsedTime(&t, g.ev[i], g.ev[i + 1]));
-        gemm_ms += t;
-    }
-    m.timing[2] = gemm_ms;
-    m.timing[3] = (double)(g.ev_used / 2);
-    m.timing[4] = g.gemm_bytes;
+    m.timing[2] = g.timer.total_ms();
+    m.timing[3] = (double)(g.timer.used / 2);
+    m.timing[4] = g.timer.bytes;
     m.timing[5] = (double)steps_done;
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);

@@ -1,0 +1,189 @@
+// Codec-decoder kernels around the large-M GEMM (qwen_tts/src/audio/decoder/v2.rs:163-247).
+//
+// Activations are channels-last, one padded strip per utterance: strip u occupies rows
+// [u*S, (u+1)*S) with P leading zero rows (the causal left padding of every conv that reads the
+// tensor, audio/tokenizer/v2/causal_conv.rs:91-101) followed by T time steps.  With that layout a
+// causal conv is a GEMM whose taps are row offsets, and a transposed conv with stride r is a GEMM with
+// N = r * Cout whose output rows are already the r-times longer sequence.
+#include "device_utils.hpp"
+#include "kernels.hpp"
+
+namespace qtts {
+
+// ------------------------------------------------------------------------------------------------
+// SplitResidualVectorQuantizer::decode (audio/quantizer.rs:417-434) with each group's 1x1 output_proj
+// folded into its codebooks at load time: x[u][t] = sum_q table[q][code[u][t][q]].
+template <typename T>
+__global__ __launch_bounds__(256) void rvq_gather_kernel(const float* __restrict__ table, const unsigned* __restrict__ codes,
+                                                         const int* __restrict__ rows, const int* __restrict__ starts,
+                                                         const int* __restrict__ lens, int Q, int csize, int Dc, int T_max,
+                                                         long S, int P, T* out, int ld) {
+    const int u = blockIdx.y, t = blockIdx.x;
+    if (t >= lens[u]) return;
+    const unsigned* c = codes + ((long)rows[u] * T_max + starts[u] + t) * Q;
+    T* o = out + ((long)u * S + P + t) * ld;
+    for (int i = threadIdx.x; i < Dc; i += blockDim.x) {
+        float s = table[((long)0 * csize + min(c[0], (unsigned)csize - 1)) * Dc + i];
+        for (int q = 1; q < Q; ++q) s = s + table[((long)q * csize + min(c[q], (unsigned)csize - 1)) * Dc + i];
+        o[i] = from_f32<T>(s);
+    }
+}
+
+void launch_rvq_gather(hipStream_t st, int dtype, const float* table, const unsigned* codes, const int* rows, const int* starts,
+                       const int* lens, int U, int Tc, int Q, int csize, int Dc, int T_max, long S, int P, void* out, int ld) {
+    QTTS_CHECK(U >= 1 && Tc >= 1 && Dc <= ld, ERR_SHAPE, "rvq_gather: bad shape");
+    dim3 grid(Tc, U);
+    if (dtype == BF16) hipLaunchKernelGGL(rvq_gather_kernel<bf16_t>, grid, dim3(256), 0, st, table, codes, rows, starts, lens, Q, csize, Dc, T_max, S, P, (bf16_t*)out, ld);
+    else hipLaunchKernelGGL(rvq_gather_kernel<float>, grid, dim3(256), 0, st, table, codes, rows, starts, lens, Q, csize, Dc, T_max, S, P, (float*)out, ld);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Epilogue of every conv GEMM: bias, optional tanh-GELU (ConvNeXt pwconv1, audio/tokenizer/v2/convnext.rs:81),
+// optional per-channel scale (ConvNeXt gamma), optional residual, then the raw result and/or its
+// SnakeBeta (audio/tokenizer/v2/snake_beta.rs:37-73: x + sin^2(x e^alpha) / (e^beta + 1e-9), in f32).
+__device__ __forceinline__ float gelu_tanh(float v) {
+    return 0.5f * v * (1.0f + tanhf(0.7978845608028654f * v * (1.0f + 0.044715f * v * v)));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_epilogue_kernel(ConvEpi e) {
+    const long total = e.M * (long)e.N / 4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long m = idx * 4 / e.N;
+        const int n = (int)(idx * 4 % e.N);
+        const long u = m / e.S_in;
+        const int tp = (int)(m % e.S_in);
+        if (tp >= e.lens[u]) continue;  // rows past the strip's last valid step only hold padding / the next strip
+        const int j = n / e.Cout, co = n % e.Cout;
+        const long orow = u * e.S_out + e.P_out + (long)tp * e.r + j;
+        const float4 a = *reinterpret_cast<const float4*>(e.acc + m * e.N + n);
+        float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float x = v[q] + (e.bias ? e.bias[co + q] : 0.f);
+            if (e.act == 1) x = gelu_tanh(x);
+            if (e.scale) x = x * e.scale[co + q];
+            if (e.resid) x = to_f32<T>(((const T*)e.resid)[orow * e.ld_out + co + q]) + x;
+            v[q] = x;
+        }
+        if (e.out) {
+            T* o = (T*)e.out + orow * e.ld_out + co;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(v[q]);
+        }
+        if (e.out_f32) {
+            float* o = e.out_f32 + orow * e.ld_out + co;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = v[q];
+        }
+        if (e.out2) {
+            T* o = (T*)e.out2 + orow * e.ld_out + co;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // the stored activation is what the reference's next op reads: round first, then SnakeBeta in f32
+                const float x = to_f32<T>(from_f32<T>(v[q]));
+                const float sn = sinf(x * e.alpha_exp[co + q]);
+                o[q] = from_f32<T>(x + sn * sn / e.beta_den[co + q]);
+            }
+        }
+    }
+}
+
+void launch_conv_epilogue(hipStream_t st, int dtype, const ConvEpi& e) {
+    QTTS_CHECK(e.N % 4 == 0 && e.Cout % 4 == 0 && e.N == e.r * e.Cout && e.M >= 1, ERR_SHAPE, "conv_epilogue: bad shape");
+    QTTS_CHECK(e.out2 == nullptr || (e.alpha_exp && e.beta_den), ERR_BAD_ARG, "conv_epilogue: snake output without parameters");
+    const long total = e.M * (long)e.N / 4;
+    const int blocks = (int)std::min<long>((total + 255) / 256, 8192);
+    if (dtype == BF16) hipLaunchKernelGGL(conv_epilogue_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, e);
+    else hipLaunchKernelGGL(conv_epilogue_kernel<float>, dim3(blocks), dim3(256), 0, st, e);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ConvNeXt front (convnext.rs:69-79): depthwise causal conv k=7 (+bias) then LayerNorm(eps 1e-6) over channels.
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(const T* __restrict__ x, const float* __restrict__ w /*[C][7]*/,
+                                                        const float* __restrict__ b, const float* __restrict__ ln_w,
+                                                        const float* __restrict__ ln_b, const int* __restrict__ lens,
+                                                        long S, int P, int C, T* out) {
+    __shared__ float red[32];
+    extern __shared__ float ybuf[];
+    const int u = blockIdx.y, t = blockIdx.x;
+    if (t >= lens[u]) return;
+    const long row = (long)u * S + P + t;
+    float sum = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = b[c];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) acc += w[c * 7 + k] * to_f32<T>(x[(row + k - 6) * C + c]);
+        ybuf[c] = acc;
+        sum += acc;
+    }
+    const float mean = block_sum(sum, red) / (float)C;
+    float var = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float d = ybuf[c] - mean;
+        var += d * d;
+    }
+    var = block_sum(var, red) / (float)C;
+    const float den = sqrtf(var + 1e-6f);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) out[row * C + c] = from_f32<T>((ybuf[c] - mean) / den * ln_w[c] + ln_b[c]);
+}
+
+void launch_dwconv_ln(hipStream_t st, int dtype, const void* x, const float* w, const float* b, const float* ln_w, const float* ln_b,
+                      const int* lens, int U, int Tmax, long S, int P, int C, void* out) {
+    QTTS_CHECK(P >= 6 && C >= 1 && C * 4 <= 64 * 1024, ERR_SHAPE, "dwconv_ln: needs 6 padding rows and C <= 16384");
+    dim3 grid(Tmax, U);
+    if (dtype == BF16) hipLaunchKernelGGL(dwconv_ln_kernel<bf16_t>, grid, dim3(256), (size_t)C * 4, st, (const bf16_t*)x, w, b, ln_w, ln_b, lens, S, P, C, (bf16_t*)out);
+    else hipLaunchKernelGGL(dwconv_ln_kernel<float>, grid, dim3(256), (size_t)C * 4, st, (const float*)x, w, b, ln_w, ln_b, lens, S, P, C, (float*)out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Final conv (C -> 1, k = 7, causal) + clamp[-1, 1] (decoder/v2.rs:238-246).  One wave per output sample group:
+// 4 lanes share a sample (each a quarter of the channels), 64 samples per block.
+template <typename T>
+__global__ __launch_bounds__(256) void final_conv_kernel(const T* __restrict__ x, const float* __restrict__ w /*[7][C]*/, float bias,
+                                                         const long* __restrict__ nvalid, long S, int P, int C, float* wav,
+                                                         long wav_stride) {
+    const int u = blockIdx.y;
+    const long t = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
+    const int part = threadIdx.x & 3;
+    const long n = nvalid[u];
+    float acc = 0.f;
+    if (t < n) {
+        const T* base = x + ((long)u * S + P + t - 6) * C;
+        const int c0 = part * (C / 4), c1 = c0 + C / 4;
+        for (int k = 0; k < 7; ++k)
+            for (int c = c0; c < c1; ++c) acc += to_f32<T>(base[(long)k * C + c]) * w[k * C + c];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (t < n && part == 0) wav[(long)u * wav_stride + t] = fminf(1.0f, fmaxf(-1.0f, acc + bias));
+}
+
+void launch_final_conv(hipStream_t st, int dtype, const void* x, const float* w, float bias, const long* nvalid, int U, long Tmax, long S,
+                       int P, int C, float* wav, long wav_stride) {
+    QTTS_CHECK(P >= 6 && C % 4 == 0 && U >= 1 && Tmax >= 1, ERR_SHAPE, "final_conv: bad shape");
+    dim3 grid((unsigned)((Tmax + 63) / 64), U);
+    if (dtype == BF16) hipLaunchKernelGGL(final_conv_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, w, bias, nvalid, S, P, C, wav, wav_stride);
+    else hipLaunchKernelGGL(final_conv_kernel<float>, grid, dim3(256), 0, st, (const float*)x, w, bias, nvalid, S, P, C, wav, wav_stride);
+}
+
+// rows of a plain [M][C] tensor <-> padded strips (used around the codec transformer)
+template <typename T>
+__global__ __launch_bounds__(256) void strip_copy_kernel(const T* __restrict__ src, T* dst, const int* __restrict__ lens,
+                                                         const int* __restrict__ row_off, long S, int P, int C, int to_strip) {
+    const int u = blockIdx.y, t = blockIdx.x;
+    if (t >= lens[u]) return;
+    const long flat = (long)row_off[u] + t, strip = (long)u * S + P + t;
+    const T* s = src + (to_strip ? flat : strip) * C;
+    T* d = dst + (to_strip ? strip : flat) * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) d[c] = s[c];
+}
+void launch_strip_copy(hipStream_t st, int dtype, const void* src, void* dst, const int* lens, const int* row_off, int U, int Tmax, long S,
+                       int P, int C, int to_strip) {
+    dim3 grid(Tmax, U);
+    if (dtype == BF16) hipLaunchKernelGGL(strip_copy_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, lens, row_off, S, P, C, to_strip);
+    else hipLaunchKernelGGL(strip_copy_kernel<float>, grid, dim3(256), 0, st, (const float*)src, (float*)dst, lens, row_off, S, P, C, to_strip);
+}
+
+}  // namespace qtts

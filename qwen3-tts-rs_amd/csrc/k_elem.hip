@@ -30,6 +30,7 @@ __device__ __forceinline__ void rmsnorm_tail(const float* xrow, float ss_local, 
 template <typename T>
 __global__ __launch_bounds__(256) void resid_norm_kernel(const float* __restrict__ resid, const float* __restrict__ part,
                                                          int KS, long ks_stride, const float* __restrict__ bias,
+                                                         const float* __restrict__ scale,
                                                          const float* __restrict__ norm_w, float eps, float* resid_out,
                                                          T* xn, float* xn_f32, int H) {
     __shared__ float red[32];
@@ -48,6 +49,10 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(const float* __restrict
             const float4 b = *reinterpret_cast<const float4*>(bias + i);
             s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
         }
+        if (scale) {
+            const float4 c = *reinterpret_cast<const float4*>(scale + i);
+            s.x *= c.x; s.y *= c.y; s.z *= c.z; s.w *= c.w;
+        }
         if (resid) {
             const float4 r = *reinterpret_cast<const float4*>(resid + row * H + i);
             s.x = r.x + s.x; s.y = r.y + s.y; s.z = r.z + s.z; s.w = r.w + s.w;
@@ -59,15 +64,15 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(const float* __restrict
 }
 
 void launch_resid_norm(hipStream_t st, int dtype, const float* resid, const float* part, int KS, long ks_stride,
-                       const float* bias, const float* norm_w, float eps, float* resid_out, void* xn, float* xn_f32, int M,
-                       int H) {
+                       const float* bias, const float* scale, const float* norm_w, float eps, float* resid_out, void* xn,
+                       float* xn_f32, int M, int H) {
     QTTS_CHECK(H % 4 == 0 && M >= 1, ERR_SHAPE, "resid_norm: H must be a multiple of 4");
     QTTS_CHECK(resid_out != nullptr && (norm_w == nullptr || xn != nullptr), ERR_BAD_ARG, "resid_norm: null output");
     if (dtype == BF16)
-        hipLaunchKernelGGL(resid_norm_kernel<bf16_t>, dim3(M), dim3(256), 0, st, resid, part, KS, ks_stride, bias, norm_w, eps,
+        hipLaunchKernelGGL(resid_norm_kernel<bf16_t>, dim3(M), dim3(256), 0, st, resid, part, KS, ks_stride, bias, scale, norm_w, eps,
                            resid_out, (bf16_t*)xn, xn_f32, H);
     else
-        hipLaunchKernelGGL(resid_norm_kernel<float>, dim3(M), dim3(256), 0, st, resid, part, KS, ks_stride, bias, norm_w, eps,
+        hipLaunchKernelGGL(resid_norm_kernel<float>, dim3(M), dim3(256), 0, st, resid, part, KS, ks_stride, bias, scale, norm_w, eps,
                            resid_out, (float*)xn, xn_f32, H);
 }
 

@@ -12,6 +12,8 @@
 // one m.  The four wave partials are summed through LDS in wave order (deterministic).
 #include "device_utils.hpp"
 #include "kernels.hpp"
+#include <cstdlib>
+#include <algorithm>
 
 namespace qtts {
 
@@ -49,7 +51,7 @@ struct Frag<float> {
     }
 };
 
-template <typename T, int MT, int NT>
+template <typename T, int MT, int NT, bool FAKEX = false>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ W, const T* __restrict__ X,
                                                           float* __restrict__ out, int N, int K, int KS, int ldx,
                                                           long out_ks_stride) {
@@ -77,17 +79,27 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ 
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
 
-    for (int c = c0; c < c1; ++c) {
-        F a[NT], b[MT];
+    // two register stages: the loads of chunk c+1 are in flight while chunk c feeds the MFMAs
+    F a0[NT], b0[MT], a1[NT], b1[MT];
+    auto load_stage = [&](F(&a)[NT], F(&b)[MT], int c) {
         const size_t off = (size_t)c * F::CHUNK;
 #pragma unroll
         for (int j = 0; j < NT; ++j) a[j].load(wp[j] + off);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) b[i].load(xp[i] + off);
+        for (int i = 0; i < MT; ++i) b[i].load(xp[i] + (FAKEX ? 0 : off));
+    };
+    auto mma_stage = [&](const F(&a)[NT], const F(&b)[MT]) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[j], b[i], acc[i][j]);
+    };
+    if (c0 < c1) load_stage(a0, b0, c0);
+    for (int c = c0; c < c1; c += 2) {
+        if (c + 1 < c1) load_stage(a1, b1, c + 1);
+        mma_stage(a0, b0);
+        if (c + 2 < c1) load_stage(a0, b0, c + 2);
+        if (c + 1 < c1) mma_stage(a1, b1);
     }
 
 #pragma unroll
@@ -109,11 +121,100 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Variant for M >= 32: the four waves of a block own different 16*NT-row slices of W and SHARE the X
+// tile through LDS, so X is read from L2 once per 64*NT weight rows instead of once per 16*NT.
+// Single phase, no loop-carried pipeline: every W load of the block's K range (NCH chunks) is issued up
+// front straight to registers, X fragment blocks are DMA'd into LDS (lane-linear 1 KiB blocks laid
+// out exactly as the MFMA B operand wants them, so the later ds_read_b128 are conflict-free), one
+// barrier, then the MFMAs run out of registers + LDS.  K is split across blocks only (grid.y).
+template <typename T, int MT, int NT, int NCH>
+__global__ __launch_bounds__(256) void gemm_ldsx_kernel(const T* __restrict__ W, const T* __restrict__ X,
+                                                        float* __restrict__ out, int N, int K, int ldx,
+                                                        long out_ks_stride) {
+    using F = Frag<T>;
+    constexpr int HALF = 16 / sizeof(T);  // elements per 16-byte half fragment
+    __shared__ uint4 xs[NCH * MT * 2 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * (64 * NT) + wave * (16 * NT);
+    const int ks = blockIdx.y;
+    const int row0 = blockIdx.z * (16 * MT);
+    const size_t kbeg = (size_t)ks * NCH * F::CHUNK;
+
+    // X fragment blocks -> LDS (asynchronous, no VGPRs)
+    constexpr int NFB = NCH * MT * 2;
+    for (int fb = wave; fb < NFB; fb += 4) {
+        const int c = fb / (MT * 2), i = (fb >> 1) % MT, h = fb & 1;
+        const T* src = X + (size_t)(row0 + 16 * i + r) * ldx + kbeg + (size_t)c * F::CHUNK + g * F::EPL + h * HALF;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(xs + fb * 64), 16, 0, 0);
+    }
+    // all W loads of this block's K range
+    F a[NCH][NT];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            a[c][j].load(W + (size_t)(n0 + 16 * j + r) * K + kbeg + (size_t)c * F::CHUNK + g * F::EPL);
+
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            F b;
+            const uint4 h0 = xs[((c * MT + i) * 2 + 0) * 64 + lane];
+            const uint4 h1 = xs[((c * MT + i) * 2 + 1) * 64 + lane];
+            __builtin_memcpy(&b, &h0, 16);
+            __builtin_memcpy((char*)&b + 16, &h1, 16);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[c][j], b, acc[i][j]);
+        }
+    }
+    float* o = out + (size_t)ks * out_ks_stride;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            *reinterpret_cast<f32x4_t*>(o + (size_t)(row0 + 16 * i + r) * N + n0 + 16 * j + 4 * g) = acc[i][j];
+}
+
+template <typename T, int MT, int NT, int NCH>
+static void launch_ldsx(hipStream_t st, const T* W, const T* X, float* out, int Mpad, int N, int K, int ldx) {
+    const int KS = K / (NCH * Frag<T>::CHUNK);
+    dim3 grid(N / (64 * NT), KS, Mpad / (16 * MT));
+    hipLaunchKernelGGL((gemm_ldsx_kernel<T, MT, NT, NCH>), grid, dim3(256), 0, st, W, X, out, N, K, ldx, (long)Mpad * N);
+}
+
+template <typename T, int MT>
+static bool launch_ldsx_mt(hipStream_t st, const T* W, const T* X, float* out, int Mpad, int N, int K, int ldx, int NT, int NCH) {
+#define QTTS_LDSX(nt, nch) if (NT == nt && NCH == nch) { launch_ldsx<T, MT, nt, nch>(st, W, X, out, Mpad, N, K, ldx); return true; }
+    QTTS_LDSX(1, 4) QTTS_LDSX(1, 8) QTTS_LDSX(2, 4) QTTS_LDSX(2, 8)
+    if constexpr (MT <= 2) { QTTS_LDSX(1, 16) }
+#undef QTTS_LDSX
+    return false;
+}
+
 template <typename T, int MT>
 static void launch_mt(hipStream_t st, const T* W, const T* X, float* out, int Mpad, int N, int K, int KS, int ldx) {
     const int Z = Mpad / (16 * MT);
     const long kstride = (long)Mpad * N;
-    if (N % 32 == 0 && (long)(N / 32) * KS * Z >= 256) {
+    static const int dbg_nt = getenv("QTTS_GEMM_NT") ? atoi(getenv("QTTS_GEMM_NT")) : 0;
+    static const int dbg_fx = getenv("QTTS_GEMM_FAKEX") ? atoi(getenv("QTTS_GEMM_FAKEX")) : 0;
+    if (dbg_nt == 4 && N % 64 == 0) {
+        dim3 grid(N / 64, KS, Z);
+        if (dbg_fx) hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 4, true>), grid, dim3(256), 0, st, W, X, out, N, K, KS, ldx, kstride);
+        else hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 4>), grid, dim3(256), 0, st, W, X, out, N, K, KS, ldx, kstride);
+    } else if (dbg_fx && N % 32 == 0) {
+        dim3 grid(N / 32, KS, Z);
+        hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 2, true>), grid, dim3(256), 0, st, W, X, out, N, K, KS, ldx, kstride);
+    } else if (N % 32 == 0 && (long)(N / 32) * KS * Z >= 256) {
         dim3 grid(N / 32, KS, Z);
         hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 2>), grid, dim3(256), 0, st, W, X, out, N, K, KS, ldx, kstride);
     } else {
@@ -129,18 +230,158 @@ static void launch_t(hipStream_t st, const T* W, const T* X, float* out, int Mpa
     else launch_mt<T, 4>(st, W, X, out, Mpad, N, K, KS, ldx);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Large-M variant (codec / speaker convolutions and transformer): rows = time positions, weights are
+// small and L2-resident, K is walked in phases of NCH chunks inside the block (no split-K slabs).
+// The X operand supports convolution addressing without im2col: with channels-last activations the
+// taps of a causal conv are row offsets, so chunk cg reads X[(m + (cg / cpt) * tap_rows)][(cg % cpt) * CHUNK ...]
+// (cpt = chunks per tap).  A plain linear layer is the single-tap case.
+template <typename T, int NT, int NCH>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(const T* __restrict__ W, const T* __restrict__ X,
+                                                        float* __restrict__ out, int N, int K, int ldx, int cpt,
+                                                        long tap_stride, long row_base) {
+    using F = Frag<T>;
+    constexpr int MT = 4;
+    constexpr int HALF = 16 / sizeof(T);
+    __shared__ uint4 xs[NCH * MT * 2 * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * (64 * NT) + wave * (16 * NT);
+    const long row0 = row_base + (long)blockIdx.y * 64;
+    const int nC = K / F::CHUNK;
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    constexpr int NFB = NCH * MT * 2;
+    for (int c0 = 0; c0 < nC; c0 += NCH) {
+        for (int fb = wave; fb < NFB; fb += 4) {
+            const int c = fb / (MT * 2), i = (fb >> 1) % MT, h = fb & 1;
+            const int cg = c0 + c;
+            const T* src = X + (row0 + 16 * i + r) * ldx + (long)(cg / cpt) * tap_stride + (long)(cg % cpt) * F::CHUNK +
+                           g * F::EPL + h * HALF;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(xs + fb * 64), 16, 0, 0);
+        }
+        F a[NCH][NT];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                a[c][j].load(W + (size_t)(n0 + 16 * j + r) * K + (size_t)(c0 + c) * F::CHUNK + g * F::EPL);
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                F b;
+                const uint4 h0 = xs[((c * MT + i) * 2 + 0) * 64 + lane];
+                const uint4 h1 = xs[((c * MT + i) * 2 + 1) * 64 + lane];
+                __builtin_memcpy(&b, &h0, 16);
+                __builtin_memcpy((char*)&b + 16, &h1, 16);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[c][j], b, acc[i][j]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            *reinterpret_cast<f32x4_t*>(out + (size_t)(row0 - row_base + 16 * i + r) * N + n0 + 16 * j + 4 * g) = acc[i][j];
+}
+
+template <typename T>
+static void launch_rows_t(hipStream_t st, const T* W, const T* X, float* out, long Mpad, int N, int K, int ldx, int cpt, long tap_stride) {
+    const int nC = K / Frag<T>::CHUNK;
+    // out rows are relative to the launch: split launches at the grid.y limit
+    for (long base = 0; base < Mpad; base += 65535L * 64) {
+        const long rows = std::min<long>(Mpad - base, 65535L * 64);
+        float* o = out + (size_t)base * N;
+        const int gy = (int)(rows / 64);
+#define QTTS_ROWS(nt, nch)                                                                                                     \
+    hipLaunchKernelGGL((gemm_rows_kernel<T, nt, nch>), dim3(N / (64 * nt), gy), dim3(256), 0, st, W, X, o, N, K, ldx, cpt, \
+                       tap_stride, base)
+        if (N % 128 == 0) {
+            if (nC % 4 == 0) QTTS_ROWS(2, 4);
+            else if (nC % 2 == 0) QTTS_ROWS(2, 2);
+            else QTTS_ROWS(2, 1);
+        } else {
+            if (nC % 4 == 0) QTTS_ROWS(1, 4);
+            else if (nC % 2 == 0) QTTS_ROWS(1, 2);
+            else QTTS_ROWS(1, 1);
+        }
+#undef QTTS_ROWS
+    }
+}
+
+// out[m][n] = sum over taps/channels; M rows padded up to 64 must be readable in X (including the tap offsets).
+void launch_gemm_rows(hipStream_t st, int dtype, const void* W, const void* X, float* out, long M, int N, int K, int ldx, int taps,
+                      long tap_stride) {
+    QTTS_CHECK(M >= 1 && N % 64 == 0 && taps >= 1 && K % taps == 0, ERR_SHAPE, "gemm_rows: N must be a multiple of 64");
+    const int chunk = dtype == BF16 ? 64 : 32;
+    QTTS_CHECK((K / taps) % chunk == 0, ERR_SHAPE, "gemm_rows: channels per tap must be a multiple of the K chunk");
+    const long Mpad = (M + 63) / 64 * 64;
+    const int cpt = K / taps / chunk;
+    if (dtype == BF16) launch_rows_t<bf16_t>(st, (const bf16_t*)W, (const bf16_t*)X, out, Mpad, N, K, ldx, cpt, tap_stride);
+    else launch_rows_t<float>(st, (const float*)W, (const float*)X, out, Mpad, N, K, ldx, cpt, tap_stride);
+}
+
 int gemm_pad_rows(int M) { return M <= 16 ? 16 : (M <= 32 ? 32 : (M + 63) / 64 * 64); }
 
-int gemm_pick_ks(int M, int N, int K, int dtype) {
+// Picks the kernel variant and the split-K factor for a shape.  Deterministic in (M, N, K, dtype) so that the
+// consumers of the partial slabs can recompute KS.
+GemmPlan gemm_plan(int M, int N, int K, int dtype) {
+    static const int force_kind = getenv("QTTS_GEMM_KIND") ? atoi(getenv("QTTS_GEMM_KIND")) : -1;
+    static const int force_nt = getenv("QTTS_GEMM_NT") ? atoi(getenv("QTTS_GEMM_NT")) : 0;
+    static const int force_nch = getenv("QTTS_GEMM_NCH") ? atoi(getenv("QTTS_GEMM_NCH")) : 0;
     const int chunk = dtype == BF16 ? 64 : 32;
     const int nC = K / chunk;
     const int Mpad = gemm_pad_rows(M);
     const int Z = Mpad <= 32 ? 1 : Mpad / 64;
+    GemmPlan p{1, 0, 1, 0};
+    if (Mpad >= 32 && force_kind != 0) {
+        // LDS-shared X: candidates ordered by preference (fewest slabs / most X reuse first)
+        const int cand[][2] = {{2, 8}, {1, 8}, {2, 4}, {1, 4}};
+        long best_blocks = -1;
+        for (auto& cnd : cand) {
+            const int nt = cnd[0], nch = cnd[1];
+            if (force_nt && nt != force_nt) continue;
+            if (force_nch && nch != force_nch) continue;
+            if (N % (64 * nt) != 0 || nC % nch != 0) continue;
+            const int ks = nC / nch;
+            if (ks > 16) continue;
+            const long blocks = (long)(N / (64 * nt)) * ks * Z;
+            if (blocks >= 448) { p = GemmPlan{ks, 1, nt, nch}; return p; }
+            if (blocks > best_blocks) { best_blocks = blocks; p = GemmPlan{ks, 1, nt, nch}; }
+        }
+        if (best_blocks >= 128 || force_kind == 1) { if (p.kind == 1) return p; }
+        p = GemmPlan{1, 0, 1, 0};
+    }
     const long nblk = (long)(N / 16) * Z;  // blocks at KS = 1 with one 16-row tile each
     int ks = 1;
     // aim for >= ~512 blocks (2 per CU) while every wave keeps at least two chunks
     while (nblk * ks < 512 && nC / (4 * ks * 2) >= 2 && ks < 16) ks *= 2;
-    return ks;
+    p.KS = ks;
+    p.kind = 0;
+    p.NT = (N % 32 == 0 && (long)(N / 32) * ks * Z >= 256) ? 2 : 1;
+    return p;
+}
+
+int gemm_pick_ks(int M, int N, int K, int dtype) { return gemm_plan(M, N, K, dtype).KS; }
+
+template <typename T>
+static void launch_plan(hipStream_t st, const GemmPlan& p, const T* W, const T* X, float* out, int Mpad, int N, int K, int ldx) {
+    if (p.kind == 1) {
+        bool ok = false;
+        if (Mpad == 32) ok = launch_ldsx_mt<T, 2>(st, W, X, out, Mpad, N, K, ldx, p.NT, p.NCH);
+        else ok = launch_ldsx_mt<T, 4>(st, W, X, out, Mpad, N, K, ldx, p.NT, p.NCH);
+        QTTS_CHECK(ok, ERR_STATE, "gemm: no kernel instance for the planned variant");
+        return;
+    }
+    launch_t<T>(st, W, X, out, Mpad, N, K, p.KS, ldx);
 }
 
 void launch_gemm(hipStream_t st, int dtype, const void* W, const void* X, float* out, int M, int N, int K, int KS, int ldx) {
@@ -148,8 +389,10 @@ void launch_gemm(hipStream_t st, int dtype, const void* W, const void* X, float*
     QTTS_CHECK(K % 64 == 0, ERR_SHAPE, "gemm: K must be a multiple of 64");
     QTTS_CHECK(KS >= 1 && M >= 1, ERR_SHAPE, "gemm: bad M/KS");
     const int Mpad = gemm_pad_rows(M);
-    if (dtype == BF16) launch_t<bf16_t>(st, (const bf16_t*)W, (const bf16_t*)X, out, Mpad, N, K, KS, ldx);
-    else launch_t<float>(st, (const float*)W, (const float*)X, out, Mpad, N, K, KS, ldx);
+    GemmPlan p = gemm_plan(M, N, K, dtype);
+    if (p.KS != KS) p = GemmPlan{KS, 0, 1, 0};  // caller forced a split factor: generic kernel
+    if (dtype == BF16) launch_plan<bf16_t>(st, p, (const bf16_t*)W, (const bf16_t*)X, out, Mpad, N, K, ldx);
+    else launch_plan<float>(st, p, (const float*)W, (const float*)X, out, Mpad, N, K, ldx);
 }
 
 }  // namespace qtts

@@ -21,17 +21,29 @@ struct KVView {
 };
 
 // ---- k_gemm.hip
+struct GemmPlan {
+    int KS, kind, NT, NCH;  // kind 0: in-block split-K kernel, 1: LDS-shared-X kernel
+};
 int gemm_pad_rows(int M);
+GemmPlan gemm_plan(int M, int N, int K, int dtype);
 int gemm_pick_ks(int M, int N, int K, int dtype);
 // out is [KS][gemm_pad_rows(M)][N] f32 partial sums; X has gemm_pad_rows(M) readable rows of ldx elements.
 void launch_gemm(hipStream_t st, int dtype, const void* W, const void* X, float* out, int M, int N, int K, int KS, int ldx);
+// Large-M GEMM with convolution addressing: out[m][n] = sum_{tap, c} X[m*ldx + tap*tap_stride + c] * W[n][tap*C + c], C = K / taps.
+// out is [ceil64(M)][N] f32; X must be readable for ceil64(M) rows plus the tap offsets.
+void launch_gemm_rows(hipStream_t st, int dtype, const void* W, const void* X, float* out, long M, int N, int K, int ldx, int taps,
+                      long tap_stride);
+
+// ---- k_bench.hip (diagnostics)
+void launch_stream(hipStream_t st, const void* src, unsigned* sink, long bytes, int blocks, int pattern, int unroll, int ld_bytes);
 
 // ---- k_elem.hip
-// x = [resid] + sum_ks part[ks] + [bias]; resid_out = x (f32, may alias resid); xn = rmsnorm(x) * w -> dtype;
+// x = [resid] + [scale *] (sum_ks part[ks] + [bias]); resid_out = x (f32, may alias resid); xn = rmsnorm(x) * w -> dtype;
 // xn_f32 (optional) receives the same normalised row in f32.
+// `scale` (optional, per channel) multiplies (sum part + bias) before the residual add (LayerScale).
 void launch_resid_norm(hipStream_t st, int dtype, const float* resid, const float* part, int KS, long ks_stride,
-                       const float* bias, const float* norm_w, float eps, float* resid_out, void* xn, float* xn_f32,
-                       int M, int H);
+                       const float* bias, const float* scale, const float* norm_w, float eps, float* resid_out, void* xn,
+                       float* xn_f32, int M, int H);
 // act = silu(sum part[..][0:I]) * sum part[..][I:2I] -> dtype   (candle_nn::ops::swiglu)
 void launch_swiglu(hipStream_t st, int dtype, const float* part, int KS, long ks_stride, void* act, int M, int I);
 // out = act(sum_ks part + bias): act 0 none, 1 silu; out_dtype F32/BF16 independent of the weight dtype
@@ -111,5 +123,31 @@ struct SampleArgs {
     int* eos_step;          // [B], -1 until the row's first EOS (only for g == 0)
 };
 void launch_sample(hipStream_t st, const SampleArgs& a);
+
+// ---- k_codec.hip
+struct ConvEpi {
+    const float* acc;        // [Mpad][N] f32; row m = u * S_in + t'
+    long M;                  // rows to visit
+    int N, r, Cout;          // N = r * Cout (r > 1: transposed conv folded into N)
+    const float* bias;       // [Cout] or null
+    const float* scale;      // [Cout] or null (ConvNeXt gamma)
+    int act;                 // 0 none, 1 tanh-GELU
+    const int* lens;         // [U] valid GEMM rows per strip
+    long S_in, S_out;        // strip lengths (rows) of the GEMM row space / of the output tensor
+    int P_out, ld_out;       // output row = u * S_out + P_out + t' * r + j ; ld_out = channel stride of out / out2 / resid
+    const void* resid;       // optional, same layout as out
+    void* out;               // model dtype, optional
+    float* out_f32;          // optional f32 copy
+    void* out2;              // optional SnakeBeta(out)
+    const float* alpha_exp;  // exp(alpha)
+    const float* beta_den;   // exp(beta) + 1e-9
+};
+void launch_conv_epilogue(hipStream_t st, int dtype, const ConvEpi& e);
+void launch_rvq_gather(hipStream_t st, int dtype, const float* table, const unsigned* codes, const int* rows, const int* starts,
+                       const int* lens, int U, int Tc, int Q, int csize, int Dc, int T_max, long S, int P, void* out, int ld);
+void launch_dwconv_ln(hipStream_t st, int dtype, const void* x, const float* w, const float* b, const float* ln_w, const float* ln_b,
+                      const int* lens, int U, int Tmax, long S, int P, int C, void* out);
+void launch_final_conv(hipStream_t st, int dtype, const void* x, const float* w, float bias, const long* nvalid, int U, long Tmax, long S,
+                       int P, int C, float* wav, long wav_stride);
 
 }  // namespace qtts

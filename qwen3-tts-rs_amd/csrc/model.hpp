@@ -102,6 +102,7 @@ struct CodecCfg {  // audio/decoder/config.rs
 struct LayerW {
     const void *qkv = nullptr, *o = nullptr, *gate_up = nullptr, *down = nullptr;  // model dtype
     const float *qkv_bias = nullptr, *o_bias = nullptr, *q_norm = nullptr, *k_norm = nullptr, *ln1 = nullptr, *ln2 = nullptr;
+    const float *ls_attn = nullptr, *ls_mlp = nullptr;  // LayerScale (codec transformer only)
 };
 
 struct StackW {

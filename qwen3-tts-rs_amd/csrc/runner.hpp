@@ -1,0 +1,111 @@
+// Shared layer runner: one pre-norm transformer layer / stack over M tokens in flight, used by the talker,
+// the code predictor and the codec's sliding-window transformer.
+#pragma once
+#include <cmath>
+#include <vector>
+
+#include "model.hpp"
+
+namespace qtts {
+
+struct Workspace {
+    DevBuf x, xn, part, q, attn, act;  // residual f32 | gemm input T | GEMM output f32 | q f32 | attn T | mlp act T
+};
+
+struct GemmTimer {
+    bool enabled = false;
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    double bytes = 0;
+    ~GemmTimer() {
+        for (auto e : ev) (void)hipEventDestroy(e);
+    }
+    double total_ms() const {
+        double ms = 0;
+        for (size_t i = 0; i + 1 < used; i += 2) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, ev[i], ev[i + 1]) == hipSuccess) ms += t;
+        }
+        return ms;
+    }
+};
+
+struct Runner {
+    Model& m;
+    Workspace& g;
+    GemmTimer* timer;
+    hipStream_t st;
+    int dt;
+    size_t es;
+    static constexpr int ROWS_KERNEL_MIN_M = 129;  // above this many tokens the large-M kernel (no split-K slabs) is used
+
+    Runner(Model& model, Workspace& ws, GemmTimer* t) : m(model), g(ws), timer(t), st(model.ctx->stream), dt(model.dtype), es(dtype_size(model.dtype)) {}
+
+    // split-K factor the consumers of g.part must assume for a GEMM of this shape
+    int ks_for(int M, int N, int K) const {
+        if (M >= ROWS_KERNEL_MIN_M && N % 64 == 0) return 1;
+        return gemm_pick_ks(M, N, K, dt);
+    }
+    long kstride(int M, int N) const { return (long)gemm_pad_rows(M) * N; }
+
+    void gemm(const void* W, const void* X, int M, int N, int K, int KS, int ldx) {
+        const bool rows = M >= ROWS_KERNEL_MIN_M && N % 64 == 0;
+        const bool time = timer && timer->enabled && timer->used + 2 <= 400000;
+        if (time) {
+            while (timer->ev.size() < timer->used + 2) {
+                hipEvent_t e;
+                QTTS_HIP(hipEventCreate(&e));
+                timer->ev.push_back(e);
+            }
+            QTTS_HIP(hipEventRecord(timer->ev[timer->used], st));
+        }
+        if (rows) launch_gemm_rows(st, dt, W, X, g.part.as<float>(), M, N, K, ldx, 1, 0);
+        else launch_gemm(st, dt, W, X, g.part.as<float>(), M, N, K, KS, ldx);
+        if (time) {
+            QTTS_HIP(hipEventRecord(timer->ev[timer->used + 1], st));
+            timer->used += 2;
+            timer->bytes += (double)N * K * es;
+        }
+    }
+
+    // One decoder layer over M tokens (nn/decoder_layer.rs:63-86; codec: audio/tokenizer/v2/transformer.rs:279-300).
+    // On entry x holds the residual stream and xn = RMSNorm_ln1(x); on exit xn = RMSNorm_next(x) with `next_norm`
+    // the following layer's input norm (or the stack's final norm).
+    void layer(const StackW& s, int l, int M, const Tok* toks, const KVView& kv, int kv_layer, const float* next_norm, void* xn_out,
+               float* xn_f32_out) {
+        const StackCfg& c = s.cfg;
+        const LayerW& w = s.layers[(size_t)l];
+        const int nq = c.nh * c.d, nqkv = (c.nh + 2 * c.nkv) * c.d;
+        int ks = ks_for(M, nqkv, c.hidden);
+        gemm(w.qkv, g.xn.p, M, nqkv, c.hidden, ks, c.hidden);
+        QkvPostArgs qa{};
+        qa.part = g.part.as<float>(); qa.KS = ks; qa.ks_stride = kstride(M, nqkv); qa.bias = w.qkv_bias;
+        qa.q_norm = w.q_norm; qa.k_norm = w.k_norm; qa.eps = c.eps; qa.cos = s.cos.as<float>(); qa.sin = s.sin.as<float>();
+        qa.rope_mode = 0; qa.toks = toks; qa.M = M; qa.nh = c.nh; qa.nkv = c.nkv; qa.d = c.d; qa.layer = kv_layer;
+        qa.q_out = g.q.as<float>();
+        launch_qkv_post(st, dt, qa, kv);
+        launch_attention(st, dt, g.q.as<float>(), toks, kv, kv_layer, M, c.nh, (float)std::pow((double)c.d, -0.5), g.attn.p);
+        ks = ks_for(M, c.hidden, nq);
+        gemm(w.o, g.attn.p, M, c.hidden, nq, ks, nq);
+        launch_resid_norm(st, dt, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), w.o_bias, w.ls_attn, w.ln2, c.eps,
+                          g.x.as<float>(), g.xn.p, nullptr, M, c.hidden);
+        ks = ks_for(M, 2 * c.inter, c.hidden);
+        gemm(w.gate_up, g.xn.p, M, 2 * c.inter, c.hidden, ks, c.hidden);
+        launch_swiglu(st, dt, g.part.as<float>(), ks, kstride(M, 2 * c.inter), g.act.p, M, c.inter);
+        ks = ks_for(M, c.hidden, c.inter);
+        gemm(w.down, g.act.p, M, c.hidden, c.inter, ks, c.inter);
+        launch_resid_norm(st, dt, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), nullptr, w.ls_mlp, next_norm, c.eps,
+                          g.x.as<float>(), xn_out, xn_f32_out, M, c.hidden);
+    }
+
+    // kv_per_layer: the KV view holds every layer (decode caches); otherwise one layer's worth is reused
+    void stack(const StackW& s, int M, const Tok* toks, const KVView& kv, void* final_xn, float* final_xn_f32, bool kv_per_layer = true) {
+        for (int l = 0; l < s.cfg.layers; ++l) {
+            const bool last = l + 1 == s.cfg.layers;
+            layer(s, l, M, toks, kv, kv_per_layer ? l : 0, last ? s.final_norm : s.layers[(size_t)l + 1].ln1, last ? final_xn : g.xn.p,
+                  last ? final_xn_f32 : nullptr);
+        }
+    }
+};
+
+}  // namespace qtts

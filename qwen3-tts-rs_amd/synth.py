@@ -337,3 +337,29 @@ def weight_bytes_per_frame(cfg, bytes_per_elem: int = 2) -> dict:
     return dict(talker=Wt * bytes_per_elem, code_predictor=((G - 1) * (Wc + Wp) + Wh) * bytes_per_elem,
                 total=(Wt + (G - 1) * (Wc + Wp) + Wh) * bytes_per_elem,
                 kv_per_token=2 * L * nkv * d * bytes_per_elem)
+
+
+def iter_weights_torch(keys, seed: int, device="cuda", bf16: bool = False):
+    """Random-init weights generated on the GPU with torch (benchmarks only: fast, but not the bit-exact
+    counter-based stream of iter_weights).  Yields (key, tensor); matrices are bf16 when `bf16`."""
+    import torch
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    for key, shape, kind in keys:
+        k = kind.split(":")
+        x = torch.randn(tuple(shape), generator=gen, device=device, dtype=torch.float32)
+        if k[0] == "normal":
+            x.mul_(float(k[1]))
+        elif k[0] == "fanin":
+            x.mul_(float(k[1]) / math.sqrt(float(np.prod(shape[1:]))))
+        elif k[0] == "fanin_t":
+            x.mul_(float(k[1]) / math.sqrt(shape[0] * shape[2] / float(k[2])))
+        elif k[0] == "ones":
+            x.mul_(float(k[1])).add_(1.0)
+        elif k[0] == "const":
+            x.mul_(float(k[2])).add_(float(k[1]))
+        elif k[0] == "usage":
+            x = x.abs().mul_(0.5).add_(1.0)
+        if bf16 and len(shape) >= 2 and "_codebook" not in key and "dwconv" not in key:
+            x = x.to(torch.bfloat16)
+        yield key, x

@@ -6,6 +6,7 @@ from oracle import bind
 from qwen3_tts_rs_amd import synth, synthetic_model, GenerationRequest, SamplingConfig
 
 def run(shape, dtype, B=2, steps=12):
+    B = int(os.environ.get("SMOKE_B", B))
     m, cfg, ccfg, tmpl = synthetic_model(shape, dtype=dtype, codec=False, round_to_bf16=(dtype == "bf16"))
     o = bind.Oracle()
     o.set_model_config(cfg)
