@@ -1,9 +1,715 @@
-// placeholder until the codec kernels land
+// 12.5 Hz codec decoder on the GPU: codes -> 24 kHz waveform (qwen_tts/src/audio/decoder/v2.rs:163-286).
+//
+// Activations are channels-last strips (one per utterance or per decode chunk) so that every conv /
+// transposed conv / linear of the decoder is one large-M GEMM (k_gemm.hip, taps = row offsets) followed by one
+// fused epilogue (k_codec.hip).  Weights are rearranged once at load time into [N][taps * Cin] rows with the
+// channel counts padded to multiples of 64; padded channels carry zeros end to end.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
 #include "generate.hpp"
+#include "runner.hpp"
+
 namespace qtts {
-struct CodecState {};
-void finalize_codec(Model&) {}
-void run_codec_decode(Model&, const uint32_t*, const int*, int, int, int, int, float*, int64_t, int64_t*) {
-    throw Error(ERR_STATE, "codec decode is not built into this library yet");
+
+namespace {
+
+constexpr int PAGE = 64;
+
+int pad64(int c) { return (c + 63) / 64 * 64; }
+
+std::vector<float> host_f32(const Model& m, const std::string& key) {
+    const Tensor& t = m.get(key);
+    const size_t n = (size_t)t.numel();
+    std::vector<float> out(n);
+    if (t.dtype == F32) {
+        QTTS_HIP(hipMemcpy(out.data(), t.buf.p, n * 4, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<uint16_t> tmp(n);
+        QTTS_HIP(hipMemcpy(tmp.data(), t.buf.p, n * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) out[i] = bf16_to_f32(tmp[i]);
+    }
+    return out;
 }
+
+void upload(DevBuf& d, const std::vector<float>& v, int dtype) {
+    if (dtype == F32) {
+        d.alloc(v.size() * 4);
+        QTTS_HIP(hipMemcpy(d.p, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    } else {
+        std::vector<uint16_t> tmp(v.size());
+        for (size_t i = 0; i < v.size(); ++i) tmp[i] = f32_to_bf16(v[i]);
+        d.alloc(tmp.size() * 2);
+        QTTS_HIP(hipMemcpy(d.p, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+    }
+}
+
+struct GemmW {
+    DevBuf w, bias;  // w: [N][K] model dtype; bias: [CoutP] f32 (zeros when absent)
+    int N = 0, K = 0, taps = 1, dil = 1, r = 1, CinP = 0, CoutP = 0;
+};
+
+struct Snake {
+    DevBuf a, den;  // exp(alpha), exp(beta) + 1e-9
+};
+
+void load_bias(const Model& m, const std::string& key, int CoutP, GemmW& g) {
+    std::vector<float> b((size_t)CoutP, 0.f);
+    if (!key.empty() && m.has(key)) {
+        const std::vector<float> src = host_f32(m, key);
+        QTTS_CHECK((int)src.size() <= CoutP, ERR_SHAPE, "bias longer than its layer: " + key);
+        std::copy(src.begin(), src.end(), b.begin());
+    }
+    upload(g.bias, b, F32);
+}
+
+// Conv1d weight (Cout, Cin, k) (candle layout, causal_conv.rs:36-60) -> W'[co][tap * CinP + ci]
+void conv_weight(const Model& m, const std::string& prefix, int dil, GemmW& g) {
+    const Tensor& t = m.get(prefix + ".weight");
+    QTTS_CHECK(t.shape.size() == 3, ERR_SHAPE, "conv weight must be rank 3: " + prefix);
+    const int Cout = (int)t.shape[0], Cin = (int)t.shape[1], k = (int)t.shape[2];
+    const std::vector<float> w = host_f32(m, prefix + ".weight");
+    g.CinP = pad64(Cin);
+    g.CoutP = pad64(Cout);
+    g.taps = k;
+    g.dil = dil;
+    g.r = 1;
+    g.N = g.CoutP;
+    g.K = k * g.CinP;
+    std::vector<float> out((size_t)g.N * g.K, 0.f);
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int j = 0; j < k; ++j) out[(size_t)co * g.K + (size_t)j * g.CinP + ci] = w[((size_t)co * Cin + ci) * k + j];
+    upload(g.w, out, m.dtype);
+    load_bias(m, prefix + ".bias", g.CoutP, g);
+}
+
+// ConvTranspose1d weight (Cin, Cout, k) with stride r, trimmed by k - r on both ends (causal_conv.rs:107-176).
+//   k == 2r: out[t' r + j] = x[t'] W[:, :, j + r] + x[t' + 1] W[:, :, j]          (two taps, T - 1 input rows)
+//   k == r:  out[t' r + j] = x[t'] W[:, :, j]                                      (one tap)
+// Either way a GEMM with N = r * CoutP: W'[j * CoutP + co][tap * CinP + ci].
+void convT_weight(const Model& m, const std::string& prefix, int r, GemmW& g) {
+    const Tensor& t = m.get(prefix + ".weight");
+    QTTS_CHECK(t.shape.size() == 3, ERR_SHAPE, "transposed conv weight must be rank 3: " + prefix);
+    const int Cin = (int)t.shape[0], Cout = (int)t.shape[1], k = (int)t.shape[2];
+    QTTS_CHECK(k == r || k == 2 * r, ERR_SHAPE, "transposed conv: only kernel == stride or kernel == 2 * stride is supported");
+    const std::vector<float> w = host_f32(m, prefix + ".weight");
+    g.CinP = pad64(Cin);
+    g.CoutP = pad64(Cout);
+    g.taps = k / r;
+    g.dil = 1;
+    g.r = r;
+    g.N = r * g.CoutP;
+    g.K = g.taps * g.CinP;
+    std::vector<float> out((size_t)g.N * g.K, 0.f);
+    for (int ci = 0; ci < Cin; ++ci)
+        for (int co = 0; co < Cout; ++co)
+            for (int j = 0; j < r; ++j) {
+                const size_t row = (size_t)j * g.CoutP + co;
+                if (g.taps == 2) {
+                    out[row * g.K + ci] = w[((size_t)ci * Cout + co) * k + j + r];
+                    out[row * g.K + g.CinP + ci] = w[((size_t)ci * Cout + co) * k + j];
+                } else {
+                    out[row * g.K + ci] = w[((size_t)ci * Cout + co) * k + j];
+                }
+            }
+    upload(g.w, out, m.dtype);
+    load_bias(m, prefix + ".bias", g.CoutP, g);
+}
+
+// Linear weight (out, in) -> padded [outP][inP]
+void linear_weight(const Model& m, const std::string& prefix, GemmW& g) {
+    const Tensor& t = m.get(prefix + ".weight");
+    QTTS_CHECK(t.shape.size() == 2, ERR_SHAPE, "linear weight must be rank 2: " + prefix);
+    const int Cout = (int)t.shape[0], Cin = (int)t.shape[1];
+    const std::vector<float> w = host_f32(m, prefix + ".weight");
+    g.CinP = pad64(Cin);
+    g.CoutP = pad64(Cout);
+    g.N = g.CoutP;
+    g.K = g.CinP;
+    std::vector<float> out((size_t)g.N * g.K, 0.f);
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci) out[(size_t)co * g.K + ci] = w[(size_t)co * Cin + ci];
+    upload(g.w, out, m.dtype);
+    load_bias(m, prefix + ".bias", g.CoutP, g);
+}
+
+void padded_vec(const Model& m, const std::string& key, int CP, float fill, DevBuf& d) {
+    std::vector<float> v = host_f32(m, key);
+    QTTS_CHECK((int)v.size() <= CP, ERR_SHAPE, "vector longer than its layer: " + key);
+    v.resize((size_t)CP, fill);
+    upload(d, v, F32);
+}
+
+void load_snake(const Model& m, const std::string& prefix, int CP, Snake& s) {
+    std::vector<float> a = host_f32(m, prefix + "alpha"), b = host_f32(m, prefix + "beta");
+    QTTS_CHECK(a.size() == b.size() && (int)a.size() <= CP, ERR_SHAPE, "snake parameters: bad shape " + prefix);
+    for (auto& v : a) v = std::exp(v);
+    for (auto& v : b) v = std::exp(v) + (float)1e-9;
+    a.resize((size_t)CP, 1.f);
+    b.resize((size_t)CP, 1.f);
+    upload(s.a, a, F32);
+    upload(s.den, b, F32);
+}
+
+}  // namespace
+
+struct CodecState {
+    int Q = 0, csize = 0, DcP = 0, latP = 0;
+    DevBuf table;  // [Q][csize][DcP] f32: codebook rows with the group's output_proj applied
+    GemmW pre_conv, in_proj, out_proj, dec0;
+    StackW xf;
+    struct Up {
+        GemmW ct, pw1, pw2;
+        DevBuf dw_w, dw_b, ln_w, ln_b, gamma;
+    };
+    std::vector<Up> ups;
+    struct Unit {
+        Snake a1, a2;
+        GemmW c1, c2;
+    };
+    struct Block {
+        Snake s0;
+        GemmW ct;
+        Unit u[3];
+    };
+    std::vector<Block> blocks;
+    Snake sfinal;
+    DevBuf final_w;  // [7][CP] f32
+    float final_b = 0.f;
+    int final_CP = 0;
+    int maxpad = 0;  // leading zero rows of the strips inside the vocoder blocks
+    // run-time buffers (grown on demand, kept between calls)
+    Workspace ws;
+    DevBuf kv, toks, ptab, meta, codes, A, Bf, R, Rf, acc, wav;
+};
+
+void finalize_codec(Model& m) {
+    if (!m.codec.present || !m.has("decoder.pre_conv.conv.weight")) return;
+    QTTS_HIP(hipSetDevice(m.ctx->device));
+    auto st = std::make_shared<CodecState>();
+    CodecState& s = *st;
+    const CodecCfg& c = m.codec;
+    QTTS_CHECK(c.hidden % 64 == 0 && c.inter % 64 == 0 && (c.heads * c.head_dim) % 64 == 0, ERR_SHAPE,
+               "codec transformer sizes must be multiples of 64");
+    QTTS_CHECK(c.codebook_dim % 2 == 0 && c.num_quantizers >= 1, ERR_SHAPE, "codec: bad quantizer shape");
+    s.Q = c.num_quantizers;
+    s.csize = c.codebook_size;
+    s.DcP = pad64(c.codebook_dim);
+    s.latP = pad64(c.latent);
+
+    // --- RVQ tables (quantizer.rs:56-59, 417-434): (embedding_sum / max(usage, 1e-5)) then the group's 1x1 output_proj
+    {
+        const int half = c.codebook_dim / 2, Dc = c.codebook_dim;
+        std::vector<float> table((size_t)s.Q * s.csize * s.DcP, 0.f);
+        const std::vector<float> p_first = host_f32(m, "decoder.quantizer.rvq_first.output_proj.weight");
+        std::vector<float> p_rest;
+        if (s.Q > 1) p_rest = host_f32(m, "decoder.quantizer.rvq_rest.output_proj.weight");
+        QTTS_CHECK((int)p_first.size() == Dc * half, ERR_SHAPE, "rvq output_proj has the wrong shape");
+        std::vector<float> e((size_t)half);
+        for (int q = 0; q < s.Q; ++q) {
+            const std::string p = q == 0 ? "decoder.quantizer.rvq_first.vq.layers.0._codebook."
+                                         : "decoder.quantizer.rvq_rest.vq.layers." + std::to_string(q - 1) + "._codebook.";
+            const std::vector<float> usage = host_f32(m, p + "cluster_usage"), sum = host_f32(m, p + "embedding_sum");
+            QTTS_CHECK((int)usage.size() == s.csize && (int)sum.size() == s.csize * half, ERR_SHAPE, "codebook has the wrong shape");
+            const std::vector<float>& proj = q == 0 ? p_first : p_rest;
+            for (int r = 0; r < s.csize; ++r) {
+                const float u = std::max(usage[(size_t)r], 1e-5f);
+                for (int i = 0; i < half; ++i) e[(size_t)i] = sum[(size_t)r * half + i] / u;
+                float* dst = &table[((size_t)q * s.csize + r) * s.DcP];
+                for (int o = 0; o < Dc; ++o) {
+                    float acc = 0.f;
+                    for (int i = 0; i < half; ++i) acc += proj[(size_t)o * half + i] * e[(size_t)i];
+                    dst[o] = acc;
+                }
+            }
+        }
+        upload(s.table, table, F32);
+    }
+    conv_weight(m, "decoder.pre_conv.conv", 1, s.pre_conv);
+    linear_weight(m, "decoder.pre_transformer.input_proj", s.in_proj);
+    linear_weight(m, "decoder.pre_transformer.output_proj", s.out_proj);
+    QTTS_CHECK(s.pre_conv.CinP == s.DcP && s.pre_conv.CoutP == s.latP && s.in_proj.CinP == s.latP && s.in_proj.CoutP == c.hidden &&
+                   s.out_proj.CinP == c.hidden && s.out_proj.CoutP == s.latP,
+               ERR_SHAPE, "codec front-end shapes do not chain");
+    // --- sliding-window transformer (audio/tokenizer/v2/transformer.rs)
+    StackCfg sc;
+    sc.hidden = c.hidden; sc.inter = c.inter; sc.layers = c.layers; sc.nh = c.heads; sc.nkv = c.kv_heads; sc.d = c.head_dim;
+    sc.eps = c.eps; sc.theta = c.rope_theta; sc.window = c.window; sc.bias = c.attention_bias;
+    QTTS_CHECK(sc.nh % sc.nkv == 0 && (sc.d == 64 || sc.d == 128), ERR_SHAPE, "codec attention geometry is not supported");
+    build_stack(m, s.xf, sc, "decoder.pre_transformer.", false, true);
+    // --- upsample stages: transposed conv (kernel == stride) + ConvNeXt block
+    for (size_t i = 0; i < c.upsampling_ratios.size(); ++i) {
+        const std::string p = "decoder.upsample." + std::to_string(i) + ".";
+        s.ups.emplace_back();
+        CodecState::Up& u = s.ups.back();
+        convT_weight(m, p + "0.conv", c.upsampling_ratios[i], u.ct);
+        QTTS_CHECK(u.ct.taps == 1 && u.ct.CinP == s.latP && u.ct.CoutP == s.latP, ERR_SHAPE, "upsample conv has the wrong shape");
+        const Tensor& dw = m.get(p + "1.dwconv.conv.weight");
+        QTTS_CHECK(dw.shape.size() == 3 && dw.shape[0] == c.latent && dw.shape[1] == 1 && dw.shape[2] == 7, ERR_SHAPE,
+                   "ConvNeXt depthwise conv must be (C, 1, 7)");
+        QTTS_CHECK(c.latent == s.latP, ERR_SHAPE, "ConvNeXt LayerNorm needs latent_dim to be a multiple of 64");
+        padded_vec(m, p + "1.dwconv.conv.weight", s.latP * 7, 0.f, u.dw_w);
+        padded_vec(m, p + "1.dwconv.conv.bias", s.latP, 0.f, u.dw_b);
+        padded_vec(m, p + "1.norm.weight", s.latP, 0.f, u.ln_w);
+        padded_vec(m, p + "1.norm.bias", s.latP, 0.f, u.ln_b);
+        padded_vec(m, p + "1.gamma", s.latP, 0.f, u.gamma);
+        linear_weight(m, p + "1.pwconv1", u.pw1);
+        linear_weight(m, p + "1.pwconv2", u.pw2);
+        QTTS_CHECK(u.pw1.CinP == s.latP && u.pw2.CoutP == s.latP && u.pw1.CoutP == u.pw2.CinP, ERR_SHAPE, "ConvNeXt MLP has the wrong shape");
+    }
+    // --- vocoder
+    conv_weight(m, "decoder.decoder.0.conv", 1, s.dec0);
+    QTTS_CHECK(s.dec0.taps == 7 && s.dec0.CinP == s.latP, ERR_SHAPE, "decoder.0 must be a k=7 conv over the latent");
+    int CP = s.dec0.CoutP;
+    s.maxpad = 0;
+    const int dils[3] = {1, 3, 9};
+    for (size_t b = 0; b < c.upsample_rates.size(); ++b) {
+        const std::string p = "decoder.decoder." + std::to_string(b + 1) + ".block.";
+        s.blocks.emplace_back();
+        CodecState::Block& blk = s.blocks.back();
+        load_snake(m, p + "0.", CP, blk.s0);
+        convT_weight(m, p + "1.conv", c.upsample_rates[b], blk.ct);
+        QTTS_CHECK(blk.ct.taps == 2 && blk.ct.CinP == CP, ERR_SHAPE, "decoder block conv must have kernel == 2 * stride");
+        CP = blk.ct.CoutP;
+        for (int u = 0; u < 3; ++u) {
+            const std::string q = p + std::to_string(u + 2) + ".";
+            load_snake(m, q + "act1.", CP, blk.u[u].a1);
+            load_snake(m, q + "act2.", CP, blk.u[u].a2);
+            conv_weight(m, q + "conv1.conv", dils[u], blk.u[u].c1);
+            conv_weight(m, q + "conv2.conv", 1, blk.u[u].c2);
+            QTTS_CHECK(blk.u[u].c1.taps == 7 && blk.u[u].c2.taps == 1 && blk.u[u].c1.CinP == CP && blk.u[u].c1.CoutP == CP &&
+                           blk.u[u].c2.CinP == CP && blk.u[u].c2.CoutP == CP,
+                       ERR_SHAPE, "residual unit has the wrong shape");
+            s.maxpad = std::max(s.maxpad, 6 * dils[u]);
+        }
+    }
+    const int nb = (int)c.upsample_rates.size();
+    load_snake(m, "decoder.decoder." + std::to_string(nb + 1) + ".", CP, s.sfinal);
+    {
+        const std::string key = "decoder.decoder." + std::to_string(nb + 2) + ".conv.";
+        const Tensor& t = m.get(key + "weight");
+        QTTS_CHECK(t.shape.size() == 3 && t.shape[0] == 1 && t.shape[2] == 7 && pad64((int)t.shape[1]) == CP, ERR_SHAPE,
+                   "final conv must be (1, C, 7)");
+        const int C = (int)t.shape[1];
+        const std::vector<float> w = host_f32(m, key + "weight");
+        std::vector<float> out((size_t)7 * CP, 0.f);
+        for (int ci = 0; ci < C; ++ci)
+            for (int k = 0; k < 7; ++k) out[(size_t)k * CP + ci] = w[(size_t)ci * 7 + k];
+        upload(s.final_w, out, F32);
+        s.final_b = host_f32(m, key + "bias")[0];
+        s.final_CP = CP;
+    }
+    m.codec_state = st;
+}
+
+namespace {
+
+struct Piece {  // one strip: a whole utterance or one window of the chunked decode
+    int row, start, len, drop_frames;
+    int64_t out_off;  // where its samples land in the row's output
+};
+
+// Strip geometry of one group of pieces: stage 0 = frame rate, then one stage per upsample block, then one per
+// vocoder block.  S = strip length in rows, P = leading zero rows, Tmax = longest valid length.
+struct Geometry {
+    int U = 0, nup = 0, nb = 0, nstage = 0;
+    std::vector<long> Tmax, S;
+    std::vector<int> P;
+    size_t act_elems = 0, acc_elems = 0, res_elems = 0;
+    long wav_max = 0;
+    size_t bytes(size_t es) const { return act_elems * es * 3 + (acc_elems + res_elems) * 4 + (size_t)U * (size_t)wav_max * 4; }
+};
+
+constexpr long SLACK_ROWS = 192;  // readable rows past the last strip: 64-row GEMM tile padding + tap offsets
+
+Geometry make_geometry(const CodecCfg& c, const CodecState& s, int U, int Tm) {
+    Geometry g;
+    g.U = U;
+    g.nup = (int)c.upsampling_ratios.size();
+    g.nb = (int)c.upsample_rates.size();
+    g.nstage = 1 + g.nup + g.nb;
+    g.Tmax.resize((size_t)g.nstage);
+    g.S.resize((size_t)g.nstage);
+    g.P.resize((size_t)g.nstage);
+    g.Tmax[0] = Tm;
+    g.P[0] = 2;  // pre_conv k = 3
+    for (int i = 0; i < g.nup; ++i) {
+        g.Tmax[(size_t)i + 1] = g.Tmax[(size_t)i] * c.upsampling_ratios[(size_t)i];
+        g.P[(size_t)i + 1] = 6;  // ConvNeXt depthwise k = 7, decoder.0 k = 7
+    }
+    for (int b = 0; b < g.nb; ++b) {
+        const int i = g.nup + b;
+        g.Tmax[(size_t)i + 1] = std::max<long>((g.Tmax[(size_t)i] - 1) * c.upsample_rates[(size_t)b], 1);
+        g.P[(size_t)i + 1] = s.maxpad;
+    }
+    for (int i = 0; i < g.nstage; ++i) g.S[(size_t)i] = g.P[(size_t)i] + g.Tmax[(size_t)i];
+    auto need = [&](long rows, int width) { g.act_elems = std::max(g.act_elems, (size_t)(rows + SLACK_ROWS) * (size_t)width); };
+    auto need_acc = [&](long M, int N) { g.acc_elems = std::max(g.acc_elems, (size_t)((M + 63) / 64 * 64) * (size_t)N); };
+    const long M0 = U * g.S[0];
+    need(M0, std::max({s.DcP, s.latP}));
+    need_acc(M0, s.latP);
+    for (int i = 0; i < g.nup; ++i) {
+        const long Min = U * g.S[(size_t)i], Mout = U * g.S[(size_t)i + 1];
+        need(Mout, s.ups[(size_t)i].pw1.CoutP);
+        need_acc(Min, s.ups[(size_t)i].ct.N);
+        need_acc(Mout, s.ups[(size_t)i].pw1.N);
+    }
+    need_acc(U * g.S[(size_t)g.nup], s.dec0.N);
+    need(U * g.S[(size_t)g.nup], s.dec0.CoutP);
+    for (int b = 0; b < g.nb; ++b) {
+        const long Min = U * g.S[(size_t)g.nup + b], Mout = U * g.S[(size_t)g.nup + b + 1];
+        need_acc(Min, s.blocks[(size_t)b].ct.N);
+        need_acc(Mout, s.blocks[(size_t)b].ct.CoutP);
+        need(Mout, s.blocks[(size_t)b].ct.CoutP);
+        g.res_elems = std::max(g.res_elems, (size_t)(Mout + SLACK_ROWS) * (size_t)s.blocks[(size_t)b].ct.CoutP);
+    }
+    g.wav_max = g.Tmax[(size_t)g.nstage - 1];
+    return g;
+}
+
+struct Decoder {
+    Model& m;
+    CodecState& s;
+    hipStream_t st;
+    int dt;
+    size_t es;
+
+    explicit Decoder(Model& model) : m(model), s(*model.codec_state), st(model.ctx->stream), dt(model.dtype), es(dtype_size(model.dtype)) {}
+
+    void gemm(const GemmW& g, const void* X, long M, int ldx) {
+        launch_gemm_rows(st, dt, g.w.p, X, s.acc.as<float>(), M, g.N, g.K, ldx, g.taps, (long)g.dil * ldx);
+    }
+    void run_group(const uint32_t* d_codes, int T_max, const std::vector<Piece>& ps, float* wav_out, int64_t wav_stride);
+};
+
+void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Piece>& ps, float* wav_out, int64_t wav_stride) {
+    const CodecCfg& c = m.codec;
+    const int U = (int)ps.size();
+    int Tm = 0;
+    for (auto& p : ps) Tm = std::max(Tm, p.len);
+    const Geometry g = make_geometry(c, s, U, Tm);
+    const int nup = g.nup, nb = g.nb, nstage = g.nstage;
+    const std::vector<long>& S = g.S;
+    const std::vector<int>& P = g.P;
+    // ---- valid lengths per stage
+    std::vector<std::vector<int>> L((size_t)nstage, std::vector<int>((size_t)U));
+    for (int u = 0; u < U; ++u) L[0][(size_t)u] = ps[(size_t)u].len;
+    for (int i = 0; i < nup; ++i)
+        for (int u = 0; u < U; ++u) L[(size_t)i + 1][(size_t)u] = L[(size_t)i][(size_t)u] * c.upsampling_ratios[(size_t)i];
+    for (int b = 0; b < nb; ++b)
+        for (int u = 0; u < U; ++u) {
+            const int i = nup + b;
+            L[(size_t)i + 1][(size_t)u] = (L[(size_t)i][(size_t)u] - 1) * c.upsample_rates[(size_t)b];
+            QTTS_CHECK(L[(size_t)i + 1][(size_t)u] >= 1, ERR_SHAPE, "codec decode: sequence too short for the vocoder's transposed convs");
+        }
+    // ---- device metadata: rows, starts, per-stage valid lengths and (valid - 1) for the two-tap transposed convs
+    std::vector<int> meta;
+    auto push = [&](const std::vector<int>& v) {
+        const size_t off = meta.size();
+        meta.insert(meta.end(), v.begin(), v.end());
+        return off;
+    };
+    std::vector<int> rows((size_t)U), starts((size_t)U);
+    for (int u = 0; u < U; ++u) {
+        rows[(size_t)u] = ps[(size_t)u].row;
+        starts[(size_t)u] = ps[(size_t)u].start;
+    }
+    const size_t o_rows = push(rows), o_starts = push(starts);
+    std::vector<size_t> o_len((size_t)nstage), o_lenm1((size_t)nstage);
+    for (int i = 0; i < nstage; ++i) {
+        o_len[(size_t)i] = push(L[(size_t)i]);
+        std::vector<int> t = L[(size_t)i];
+        for (auto& v : t) v -= 1;
+        o_lenm1[(size_t)i] = push(t);
+    }
+    s.meta.ensure(meta.size() * 4);
+    QTTS_HIP(hipMemcpyAsync(s.meta.p, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, st));
+    QTTS_HIP(hipStreamSynchronize(st));  // `meta` is a local
+    const int* d_meta = s.meta.as<int>();
+    auto d_len = [&](int i) { return d_meta + o_len[(size_t)i]; };
+    auto d_lenm1 = [&](int i) { return d_meta + o_lenm1[(size_t)i]; };
+
+    s.A.ensure(g.act_elems * es);
+    s.Bf.ensure(g.act_elems * es);
+    s.R.ensure(g.act_elems * es);
+    s.Rf.ensure(g.res_elems * 4);  // the vocoder's residual stream is kept in f32
+    s.acc.ensure(g.acc_elems * 4);
+    s.wav.ensure((size_t)U * (size_t)g.wav_max * 4);
+
+    // ================= stage 0: RVQ lookup -> pre_conv -> transformer =================
+    const long M0 = U * S[0];
+    const int Hd = c.hidden;
+    QTTS_HIP(hipMemsetAsync(s.A.p, 0, (size_t)(M0 + SLACK_ROWS) * s.DcP * es, st));
+    launch_rvq_gather(st, dt, s.table.as<float>(), d_codes, d_meta + o_rows, d_meta + o_starts, d_len(0), U, Tm, s.Q, s.csize, s.DcP,
+                      T_max, S[0], P[0], s.A.p, s.DcP);
+    // pre_conv (k = 3): acc row (u, t) reads strip rows t .. t + 2 (two leading zero rows)
+    gemm(s.pre_conv, s.A.p, M0, s.DcP);
+    QTTS_HIP(hipMemsetAsync(s.Bf.p, 0, (size_t)(M0 + SLACK_ROWS) * s.latP * es, st));
+    {
+        ConvEpi e{};
+        e.acc = s.acc.as<float>(); e.M = M0; e.N = s.pre_conv.N; e.r = 1; e.Cout = s.pre_conv.CoutP; e.bias = s.pre_conv.bias.as<float>();
+        e.lens = d_len(0); e.S_in = S[0]; e.S_out = S[0]; e.P_out = 0; e.ld_out = s.latP; e.out = s.Bf.p;
+        launch_conv_epilogue(st, dt, e);
+    }
+    // transformer over every strip row (rows past a strip's length are computed and ignored)
+    {
+        QTTS_CHECK(M0 < (1L << 30), ERR_SHAPE, "codec decode: group too large");
+        const int M = (int)M0;
+        const size_t rp = (size_t)gemm_pad_rows(M) + 64;
+        const int nqkv = (c.heads + 2 * c.kv_heads) * c.head_dim, nq = c.heads * c.head_dim;
+        const int Nmax = std::max({nqkv, 2 * c.inter, Hd, s.latP});
+        s.ws.x.ensure(rp * Hd * 4);
+        s.ws.xn.ensure(rp * Hd * es);
+        s.ws.part.ensure((size_t)Nmax * std::max(rp, (size_t)16 * std::min<size_t>(rp, 256)) * 4);
+        s.ws.q.ensure(rp * nq * 4);
+        s.ws.attn.ensure(rp * nq * es);
+        s.ws.act.ensure(rp * c.inter * es);
+        // pages: one private range per strip + one shared dump page for the padding rows
+        const int pp = (Tm + PAGE - 1) / PAGE;
+        std::vector<int> ptab((size_t)(U + 1) * pp);
+        for (int u = 0; u < U; ++u)
+            for (int i = 0; i < pp; ++i) ptab[(size_t)u * pp + i] = u * pp + i;
+        for (int i = 0; i < pp; ++i) ptab[(size_t)U * pp + i] = U * pp;
+        std::vector<Tok> toks((size_t)M);
+        for (int u = 0; u < U; ++u)
+            for (long r = 0; r < S[0]; ++r) {
+                Tok& t = toks[(size_t)(u * S[0] + r)];
+                if (r < L[0][(size_t)u]) {
+                    const int pos = (int)r, lo = std::max(0, pos + 1 - c.window);
+                    t = Tok{u, pos, lo, pos + 1 - lo};
+                } else {
+                    const int slot = (int)((u * S[0] + r) % PAGE);
+                    t = Tok{U, slot, slot, 1};
+                }
+            }
+        const size_t page_elems = (size_t)2 * c.kv_heads * PAGE * c.head_dim;
+        s.kv.ensure(((size_t)U * pp + 1) * page_elems * es);
+        s.ptab.ensure(ptab.size() * 4);
+        s.toks.ensure(toks.size() * sizeof(Tok));
+        QTTS_HIP(hipMemcpyAsync(s.ptab.p, ptab.data(), ptab.size() * 4, hipMemcpyHostToDevice, st));
+        QTTS_HIP(hipMemcpyAsync(s.toks.p, toks.data(), toks.size() * sizeof(Tok), hipMemcpyHostToDevice, st));
+        QTTS_HIP(hipStreamSynchronize(st));  // ptab / toks are locals
+        KVView kv{s.kv.p, 0, PAGE, c.kv_heads, c.head_dim, pp, s.ptab.as<int>()};
+        if (s.xf.max_pos < std::max(Tm, PAGE)) {
+            int n = 256;
+            while (n < Tm) n *= 2;
+            std::vector<float> cs, sn;
+            rope_table_simple(c.head_dim, c.rope_theta, n, cs, sn);
+            s.xf.cos.alloc(cs.size() * 4);
+            s.xf.sin.alloc(sn.size() * 4);
+            QTTS_HIP(hipMemcpy(s.xf.cos.p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
+            QTTS_HIP(hipMemcpy(s.xf.sin.p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+            s.xf.max_pos = n;
+        }
+        Runner run(m, s.ws, nullptr);
+        // input_proj (+bias) starts the residual stream
+        int ks = run.ks_for(M, Hd, s.latP);
+        run.gemm(s.in_proj.w.p, s.Bf.p, M, Hd, s.latP, ks, s.latP);
+        launch_resid_norm(st, dt, nullptr, s.ws.part.as<float>(), ks, run.kstride(M, Hd), s.in_proj.bias.as<float>(), nullptr,
+                          s.xf.layers[0].ln1, c.eps, s.ws.x.as<float>(), s.ws.xn.p, nullptr, M, Hd);
+        run.stack(s.xf, M, s.toks.as<Tok>(), kv, s.ws.xn.p, nullptr, false);
+        // output_proj (+bias) -> strips without padding (the next op is a kernel == stride transposed conv)
+        ks = run.ks_for(M, s.latP, Hd);
+        run.gemm(s.out_proj.w.p, s.ws.xn.p, M, s.latP, Hd, ks, Hd);
+        const float* acc = s.ws.part.as<float>();
+        if (ks != 1) {  // fold the split-K slabs so that the conv epilogue sees one [M][N] matrix
+            launch_bias_act(st, s.ws.part.as<float>(), ks, run.kstride(M, s.latP), nullptr, 0, s.acc.p, F32, M, s.latP);
+            acc = s.acc.as<float>();
+        }
+        ConvEpi e{};
+        e.acc = acc; e.M = M0; e.N = s.latP; e.r = 1; e.Cout = s.latP; e.bias = s.out_proj.bias.as<float>();
+        e.lens = d_len(0); e.S_in = S[0]; e.S_out = S[0]; e.P_out = 0; e.ld_out = s.latP; e.out = s.A.p;
+        launch_conv_epilogue(st, dt, e);
+    }
+    // ================= upsample stages: the current tensor lives in A with Pcur leading rows per strip =================
+    int Pcur = 0;
+    for (int i = 0; i < nup; ++i) {
+        const CodecState::Up& up = s.ups[(size_t)i];
+        const long Min = U * S[(size_t)i], Mout = U * S[(size_t)i + 1];
+        const int Pn = P[(size_t)i + 1];
+        // transposed conv (kernel == stride): A -> R (strips with six leading zero rows for the depthwise conv)
+        gemm(up.ct, (const char*)s.A.p + (size_t)Pcur * s.latP * es, Min, s.latP);
+        QTTS_HIP(hipMemsetAsync(s.R.p, 0, (size_t)(Mout + SLACK_ROWS) * s.latP * es, st));
+        {
+            ConvEpi e{};
+            e.acc = s.acc.as<float>(); e.M = Min; e.N = up.ct.N; e.r = up.ct.r; e.Cout = up.ct.CoutP; e.bias = up.ct.bias.as<float>();
+            e.lens = d_len(i); e.S_in = S[(size_t)i]; e.S_out = S[(size_t)i + 1]; e.P_out = Pn; e.ld_out = s.latP; e.out = s.R.p;
+            launch_conv_epilogue(st, dt, e);
+        }
+        // ConvNeXt: depthwise conv + LayerNorm -> A ; pwconv1 + GELU -> Bf ; pwconv2 * gamma + residual -> R (in place)
+        launch_dwconv_ln(st, dt, s.R.p, up.dw_w.as<float>(), up.dw_b.as<float>(), up.ln_w.as<float>(), up.ln_b.as<float>(), d_len(i + 1), U,
+                         (int)g.Tmax[(size_t)i + 1], S[(size_t)i + 1], Pn, s.latP, s.A.p);
+        gemm(up.pw1, (const char*)s.A.p + (size_t)Pn * s.latP * es, Mout, s.latP);
+        {
+            ConvEpi e{};
+            e.acc = s.acc.as<float>(); e.M = Mout; e.N = up.pw1.N; e.r = 1; e.Cout = up.pw1.CoutP; e.bias = up.pw1.bias.as<float>();
+            e.act = 1; e.lens = d_len(i + 1); e.S_in = S[(size_t)i + 1]; e.S_out = S[(size_t)i + 1]; e.P_out = 0; e.ld_out = up.pw1.CoutP;
+            e.out = s.Bf.p;
+            launch_conv_epilogue(st, dt, e);
+        }
+        gemm(up.pw2, s.Bf.p, Mout, up.pw1.CoutP);
+        {
+            ConvEpi e{};
+            e.acc = s.acc.as<float>(); e.M = Mout; e.N = up.pw2.N; e.r = 1; e.Cout = up.pw2.CoutP; e.bias = up.pw2.bias.as<float>();
+            e.scale = up.gamma.as<float>(); e.resid = s.R.p; e.lens = d_len(i + 1); e.S_in = S[(size_t)i + 1]; e.S_out = S[(size_t)i + 1];
+            e.P_out = Pn; e.ld_out = s.latP; e.out = s.R.p;
+            launch_conv_epilogue(st, dt, e);
+        }
+        std::swap(s.A, s.R);  // the stage's result becomes the current tensor
+        Pcur = Pn;
+    }
+    // ================= vocoder =================
+    QTTS_CHECK(Pcur >= 6, ERR_STATE, "codec decode: decoder.0 needs six leading zero rows (no upsample stage configured?)");
+    int CP = s.dec0.CoutP;
+    {
+        // decoder.0 (k = 7): A -> snake(block 1 .0) in Bf; the raw result is not needed again
+        const long M = U * S[(size_t)nup];
+        gemm(s.dec0, (const char*)s.A.p + (size_t)(Pcur - 6) * s.latP * es, M, s.latP);
+        ConvEpi e{};
+        e.acc = s.acc.as<float>(); e.M = M; e.N = s.dec0.N; e.r = 1; e.Cout = CP; e.bias = s.dec0.bias.as<float>();
+        e.lens = d_len(nup); e.S_in = S[(size_t)nup]; e.S_out = S[(size_t)nup]; e.P_out = 0; e.ld_out = CP;
+        e.out2 = s.Bf.p; e.alpha_exp = s.blocks[0].s0.a.as<float>(); e.beta_den = s.blocks[0].s0.den.as<float>();
+        launch_conv_epilogue(st, dt, e);
+    }
+    // Inside a block R is the residual stream and A the activated input of the next conv, both with maxpad leading
+    // zero rows per strip.  `xin` is the activated input of the block's transposed conv: Bf for the first block,
+    // afterwards the previous block's A viewed from its first valid row.
+    const char* xin = (const char*)s.Bf.p;
+    for (int b = 0; b < nb; ++b) {
+        const CodecState::Block& blk = s.blocks[(size_t)b];
+        const int si = nup + b, so = si + 1;
+        const long Min = U * S[(size_t)si], Mout = U * S[(size_t)so];
+        const int Pn = P[(size_t)so];
+        const int CPo = blk.ct.CoutP;
+        gemm(blk.ct, xin, Min, CP);
+        QTTS_HIP(hipMemsetAsync(s.A.p, 0, (size_t)(Mout + SLACK_ROWS) * CPo * es, st));
+        {
+            ConvEpi e{};
+            e.acc = s.acc.as<float>(); e.M = Min; e.N = blk.ct.N; e.r = blk.ct.r; e.Cout = CPo; e.bias = blk.ct.bias.as<float>();
+            e.lens = d_lenm1(si); e.S_in = S[(size_t)si]; e.S_out = S[(size_t)so]; e.P_out = Pn; e.ld_out = CPo;
+            e.out_f32 = s.Rf.as<float>(); e.out2 = s.A.p; e.alpha_exp = blk.u[0].a1.a.as<float>(); e.beta_den = blk.u[0].a1.den.as<float>();
+            launch_conv_epilogue(st, dt, e);
+        }
+        for (int u = 0; u < 3; ++u) {
+            const CodecState::Unit& un = blk.u[u];
+            // conv1 (k = 7, dilated): A -> snake(act2) in Bf
+            gemm(un.c1, (const char*)s.A.p + (size_t)(Pn - 6 * un.c1.dil) * CPo * es, Mout, CPo);
+            {
+                ConvEpi e{};
+                e.acc = s.acc.as<float>(); e.M = Mout; e.N = CPo; e.r = 1; e.Cout = CPo; e.bias = un.c1.bias.as<float>();
+                e.lens = d_len(so); e.S_in = S[(size_t)so]; e.S_out = S[(size_t)so]; e.P_out = 0; e.ld_out = CPo;
+                e.out2 = s.Bf.p; e.alpha_exp = un.a2.a.as<float>(); e.beta_den = un.a2.den.as<float>();
+                launch_conv_epilogue(st, dt, e);
+            }
+            // conv2 (k = 1) + residual: R += conv2(Bf); A = snake_next(R).  After the last unit the raw sum is dead.
+            gemm(un.c2, s.Bf.p, Mout, CPo);
+            {
+                ConvEpi e{};
+                e.acc = s.acc.as<float>(); e.M = Mout; e.N = CPo; e.r = 1; e.Cout = CPo; e.bias = un.c2.bias.as<float>();
+                e.resid_f32 = s.Rf.as<float>(); e.lens = d_len(so); e.S_in = S[(size_t)so]; e.S_out = S[(size_t)so]; e.P_out = Pn; e.ld_out = CPo;
+                const Snake& nx = u < 2 ? blk.u[u + 1].a1 : (b + 1 < nb ? s.blocks[(size_t)b + 1].s0 : s.sfinal);
+                e.alpha_exp = nx.a.as<float>(); e.beta_den = nx.den.as<float>();
+                e.out_f32 = s.Rf.as<float>();
+                e.out2 = s.A.p;
+                launch_conv_epilogue(st, dt, e);
+            }
+        }
+        CP = CPo;
+        if (b + 1 < nb) {
+            // the next block overwrites A and R only after its transposed-conv GEMM has consumed xin, but its epilogue
+            // writes A while nothing reads it any more; Bf takes over as the activation buffer to keep xin intact
+            std::swap(s.A, s.Bf);
+            xin = (const char*)s.Bf.p + (size_t)Pn * CP * es;
+        }
+    }
+    // ================= final conv (C -> 1, k = 7) + clamp =================
+    const int last = nstage - 1;
+    launch_final_conv(st, dt, s.A.p, s.final_w.as<float>(), s.final_b, d_len(last), U, g.Tmax[(size_t)last], S[(size_t)last], P[(size_t)last],
+                      s.final_CP, s.wav.as<float>(), g.wav_max);
+    const long up_total = c.total_upsample();
+    for (int u = 0; u < U; ++u) {
+        const Piece& p = ps[(size_t)u];
+        const long drop = (long)p.drop_frames * up_total, n = L[(size_t)last][(size_t)u] - drop;
+        QTTS_CHECK(n >= 0, ERR_SHAPE, "codec decode: chunk shorter than its context");
+        QTTS_CHECK(p.out_off + n <= wav_stride, ERR_SHAPE, "codec decode: wav_stride too small");
+        if (n > 0)
+            QTTS_HIP(hipMemcpyAsync(wav_out + (size_t)p.row * wav_stride + p.out_off, s.wav.as<float>() + (size_t)u * g.wav_max + drop,
+                                    (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    }
+    QTTS_HIP(hipStreamSynchronize(st));
+}
+
+}  // namespace
+
+// Model::decode_output / TokenizerV2::{decode, chunked_decode} (model/generate.rs:29-143, audio/decoder/v2.rs:163-286).
+void run_codec_decode(Model& m, const uint32_t* codes, const int* lens, int B, int T_max, int chunk, int left_ctx, float* wav_out,
+                      int64_t wav_stride, int64_t* wav_lens) {
+    QTTS_CHECK(m.finalized && m.codec_state, ERR_STATE, "codec weights are not loaded");
+    QTTS_CHECK(B >= 1 && T_max >= 1 && wav_stride >= 1, ERR_BAD_ARG, "codec decode: bad batch shape");
+    QTTS_CHECK(chunk == -2 || chunk <= 0 || left_ctx >= 0, ERR_BAD_ARG, "codec decode: negative left context");
+    QTTS_HIP(hipSetDevice(m.ctx->device));
+    CodecState& s = *m.codec_state;
+    const CodecCfg& c = m.codec;
+    const long up_total = c.total_upsample();
+    // every code id is validated on the host (quantizer lookups index device tables with them)
+    for (int b = 0; b < B; ++b) {
+        QTTS_CHECK(lens[b] >= 0 && lens[b] <= T_max, ERR_BAD_ARG, "codec decode: lens out of range");
+        const uint32_t* row = codes + (size_t)b * T_max * s.Q;
+        for (size_t i = 0; i < (size_t)lens[b] * s.Q; ++i)
+            QTTS_CHECK(row[i] < (uint32_t)s.csize, ERR_BAD_ARG, "codec decode: code id out of range");
+    }
+    // ---- pieces
+    std::vector<Piece> pieces;
+    // samples one decode of n frames yields: every kernel == 2 * stride transposed conv drops one input step
+    auto samples_of = [&](int n) {
+        long L = n;
+        for (int r : c.upsampling_ratios) L *= r;
+        for (int r : c.upsample_rates) L = (L - 1) * r;
+        return L;
+    };
+    for (int b = 0; b < B; ++b) {
+        const int len = lens[b];
+        wav_lens[b] = 0;
+        if (len == 0) continue;
+        int ch = chunk, ctx = left_ctx;
+        if (chunk == -2) {  // decode_output policy (model/generate.rs:71-111)
+            if (len > 512) { ch = 256; ctx = 32; } else ch = 0;
+        }
+        if (ch <= 0) {
+            pieces.push_back(Piece{b, 0, len, 0, 0});
+            wav_lens[b] = samples_of(len);
+        } else {
+            int64_t off = 0;
+            for (int start = 0; start < len; start += ch) {
+                const int end = std::min(start + ch, len);
+                const int cx = start > ctx ? ctx : start;
+                const long n = samples_of(end - start + cx) - (long)cx * up_total;
+                QTTS_CHECK(n >= 0, ERR_SHAPE, "codec decode: chunk shorter than its context");
+                pieces.push_back(Piece{b, start - cx, end - start + cx, cx, off});
+                off += n;
+            }
+            wav_lens[b] = off;
+        }
+        QTTS_CHECK(wav_lens[b] <= wav_stride, ERR_SHAPE, "codec decode: wav_stride too small for the decoded length");
+    }
+    if (pieces.empty()) return;
+    std::stable_sort(pieces.begin(), pieces.end(), [](const Piece& a, const Piece& b) { return a.len > b.len; });
+    s.codes.ensure((size_t)B * T_max * s.Q * 4);
+    QTTS_HIP(hipMemcpy(s.codes.p, codes, (size_t)B * T_max * s.Q * 4, hipMemcpyHostToDevice));
+    // ---- groups bounded by a scratch budget
+    static const size_t budget = (size_t)(getenv("QTTS_CODEC_SCRATCH_MB") ? std::max(64, atoi(getenv("QTTS_CODEC_SCRATCH_MB"))) : 32768) << 20;
+    Decoder dec(m);
+    size_t i = 0;
+    while (i < pieces.size()) {
+        const int Tm = pieces[i].len;  // sorted: the first piece of a group is its longest
+        size_t n = 1;
+        while (i + n < pieces.size() && n < 4096 && make_geometry(c, s, (int)n + 1, Tm).bytes(dec.es) <= budget) ++n;
+        std::vector<Piece> grp(pieces.begin() + (long)i, pieces.begin() + (long)(i + n));
+        dec.run_group(s.codes.as<uint32_t>(), T_max, grp, wav_out, wav_stride);
+        i += n;
+    }
+}
+
 }  // namespace qtts

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void conv_epilogue_kernel(ConvEpi e) {
             if (e.act == 1) x = gelu_tanh(x);
             if (e.scale) x = x * e.scale[co + q];
             if (e.resid) x = to_f32<T>(((const T*)e.resid)[orow * e.ld_out + co + q]) + x;
+            if (e.resid_f32) x = e.resid_f32[orow * e.ld_out + co + q] + x;
             v[q] = x;
         }
         if (e.out) {
@@ -80,8 +81,8 @@ __global__ __launch_bounds__(256) void conv_epilogue_kernel(ConvEpi e) {
             T* o = (T*)e.out2 + orow * e.ld_out + co;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                // the stored activation is what the reference's next op reads: round first, then SnakeBeta in f32
-                const float x = to_f32<T>(from_f32<T>(v[q]));
+                // SnakeBeta in f32 on the value the next op would read: the stored (rounded) one unless an f32 copy is kept
+                const float x = e.out_f32 ? v[q] : to_f32<T>(from_f32<T>(v[q]));
                 const float sn = sinf(x * e.alpha_exp[co + q]);
                 o[q] = from_f32<T>(x + sn * sn / e.beta_den[co + q]);
             }
@@ -142,7 +143,7 @@ void launch_dwconv_ln(hipStream_t st, int dtype, const void* x, const float* w, 
 // 4 lanes share a sample (each a quarter of the channels), 64 samples per block.
 template <typename T>
 __global__ __launch_bounds__(256) void final_conv_kernel(const T* __restrict__ x, const float* __restrict__ w /*[7][C]*/, float bias,
-                                                         const long* __restrict__ nvalid, long S, int P, int C, float* wav,
+                                                         const int* __restrict__ nvalid, long S, int P, int C, float* wav,
                                                          long wav_stride) {
     const int u = blockIdx.y;
     const long t = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
@@ -160,30 +161,12 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const T* __restrict__ x
     if (t < n && part == 0) wav[(long)u * wav_stride + t] = fminf(1.0f, fmaxf(-1.0f, acc + bias));
 }
 
-void launch_final_conv(hipStream_t st, int dtype, const void* x, const float* w, float bias, const long* nvalid, int U, long Tmax, long S,
+void launch_final_conv(hipStream_t st, int dtype, const void* x, const float* w, float bias, const int* nvalid, int U, long Tmax, long S,
                        int P, int C, float* wav, long wav_stride) {
     QTTS_CHECK(P >= 6 && C % 4 == 0 && U >= 1 && Tmax >= 1, ERR_SHAPE, "final_conv: bad shape");
     dim3 grid((unsigned)((Tmax + 63) / 64), U);
     if (dtype == BF16) hipLaunchKernelGGL(final_conv_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, w, bias, nvalid, S, P, C, wav, wav_stride);
     else hipLaunchKernelGGL(final_conv_kernel<float>, grid, dim3(256), 0, st, (const float*)x, w, bias, nvalid, S, P, C, wav, wav_stride);
-}
-
-// rows of a plain [M][C] tensor <-> padded strips (used around the codec transformer)
-template <typename T>
-__global__ __launch_bounds__(256) void strip_copy_kernel(const T* __restrict__ src, T* dst, const int* __restrict__ lens,
-                                                         const int* __restrict__ row_off, long S, int P, int C, int to_strip) {
-    const int u = blockIdx.y, t = blockIdx.x;
-    if (t >= lens[u]) return;
-    const long flat = (long)row_off[u] + t, strip = (long)u * S + P + t;
-    const T* s = src + (to_strip ? flat : strip) * C;
-    T* d = dst + (to_strip ? strip : flat) * C;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) d[c] = s[c];
-}
-void launch_strip_copy(hipStream_t st, int dtype, const void* src, void* dst, const int* lens, const int* row_off, int U, int Tmax, long S,
-                       int P, int C, int to_strip) {
-    dim3 grid(Tmax, U);
-    if (dtype == BF16) hipLaunchKernelGGL(strip_copy_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, lens, row_off, S, P, C, to_strip);
-    else hipLaunchKernelGGL(strip_copy_kernel<float>, grid, dim3(256), 0, st, (const float*)src, (float*)dst, lens, row_off, S, P, C, to_strip);
 }
 
 }  // namespace qtts

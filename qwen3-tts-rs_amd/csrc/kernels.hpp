@@ -135,7 +135,8 @@ struct ConvEpi {
     const int* lens;         // [U] valid GEMM rows per strip
     long S_in, S_out;        // strip lengths (rows) of the GEMM row space / of the output tensor
     int P_out, ld_out;       // output row = u * S_out + P_out + t' * r + j ; ld_out = channel stride of out / out2 / resid
-    const void* resid;       // optional, same layout as out
+    const void* resid;       // optional, same layout as out (model dtype)
+    const float* resid_f32;  // optional, same layout as out (f32)
     void* out;               // model dtype, optional
     float* out_f32;          // optional f32 copy
     void* out2;              // optional SnakeBeta(out)
@@ -147,7 +148,7 @@ void launch_rvq_gather(hipStream_t st, int dtype, const float* table, const unsi
                        const int* lens, int U, int Tc, int Q, int csize, int Dc, int T_max, long S, int P, void* out, int ld);
 void launch_dwconv_ln(hipStream_t st, int dtype, const void* x, const float* w, const float* b, const float* ln_w, const float* ln_b,
                       const int* lens, int U, int Tmax, long S, int P, int C, void* out);
-void launch_final_conv(hipStream_t st, int dtype, const void* x, const float* w, float bias, const long* nvalid, int U, long Tmax, long S,
+void launch_final_conv(hipStream_t st, int dtype, const void* x, const float* w, float bias, const int* nvalid, int U, long Tmax, long S,
                        int P, int C, float* wav, long wav_stride);
 
 }  // namespace qtts

@@ -211,7 +211,7 @@ void Model::ensure_rope(StackW& s, int max_pos) {
     s.max_pos = n;
 }
 
-static void build_stack(Model& m, StackW& s, const StackCfg& c, const std::string& prefix) {
+void build_stack(Model& m, StackW& s, const StackCfg& c, const std::string& prefix, bool qk_norm, bool layer_scale) {
     s.cfg = c;
     s.layers.resize((size_t)c.layers);
     const size_t es = dtype_size(m.dtype);
@@ -244,8 +244,14 @@ static void build_stack(Model& m, StackW& s, const StackCfg& c, const std::strin
         m.owned.push_back(std::move(gu));
         w.o = m.mat(p + "self_attn.o_proj.weight");
         w.down = m.mat(p + "mlp.down_proj.weight");
-        w.q_norm = m.f32(p + "self_attn.q_norm.weight");
-        w.k_norm = m.f32(p + "self_attn.k_norm.weight");
+        if (qk_norm) {
+            w.q_norm = m.f32(p + "self_attn.q_norm.weight");
+            w.k_norm = m.f32(p + "self_attn.k_norm.weight");
+        }
+        if (layer_scale) {  // audio/tokenizer/v2/transformer.rs:279-300
+            w.ls_attn = m.f32(p + "self_attn_layer_scale.scale");
+            w.ls_mlp = m.f32(p + "mlp_layer_scale.scale");
+        }
         w.ln1 = m.f32(p + "input_layernorm.weight");
         w.ln2 = m.f32(p + "post_attention_layernorm.weight");
         if (c.bias) {
@@ -274,8 +280,8 @@ void Model::finalize() {
     QTTS_HIP(hipSetDevice(ctx->device));
     const bool have_talker = has("talker.model.norm.weight");
     if (have_talker) {
-        build_stack(*this, talker, cfg.talker, "talker.model.");
-        build_stack(*this, cp, cfg.cp, "talker.code_predictor.model.");
+        build_stack(*this, talker, cfg.talker, "talker.model.", true, false);
+        build_stack(*this, cp, cfg.cp, "talker.code_predictor.model.", true, false);
         const int H = cfg.talker.hidden, Ht = cfg.text_hidden, Hc = cfg.cp.hidden, G = cfg.groups;
         expect_shape(get("talker.model.codec_embedding.weight"), "talker.model.codec_embedding.weight", {cfg.vocab, H});
         expect_shape(get("talker.model.text_embedding.weight"), "talker.model.text_embedding.weight", {cfg.text_vocab, Ht});

@@ -148,6 +148,9 @@ struct Model {
     void ensure_rope(StackW& s, int max_pos);
 };
 
+// Fuses q|k|v and gate|up of every layer under `prefix` and fills the per-layer weight table.
+void build_stack(Model& m, StackW& s, const StackCfg& c, const std::string& prefix, bool qk_norm, bool layer_scale);
+
 // cos/sin tables on the host exactly as the reference computes them
 void rope_table_default(int d, double theta, int max_pos, std::vector<float>& cos, std::vector<float>& sin);  // rope/core.rs:150-160
 void rope_table_simple(int d, double theta, int max_pos, std::vector<float>& cos, std::vector<float>& sin);   // rope/simple.rs:30-64

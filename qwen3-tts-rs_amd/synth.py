@@ -295,11 +295,11 @@ def codec_keys(codec_cfg):
             R = B + f"{u + 2}."
             ks += [(P + R + "act1.alpha", (nxt,), "normal:0.3"), (P + R + "act1.beta", (nxt,), "normal:0.3"),
                    (P + R + "act2.alpha", (nxt,), "normal:0.3"), (P + R + "act2.beta", (nxt,), "normal:0.3")]
-            ks += conv(R + "conv1", nxt, nxt, 7, "0.7") + conv(R + "conv2", nxt, nxt, 1, "0.7")
+            ks += conv(R + "conv1", nxt, nxt, 7, "0.7") + conv(R + "conv2", nxt, nxt, 1, "0.3")
         cur = nxt
     nb = len(c["upsample_rates"])
     ks += [(P + f"decoder.{nb + 1}.alpha", (cur,), "normal:0.3"), (P + f"decoder.{nb + 1}.beta", (cur,), "normal:0.3")]
-    ks += conv(f"decoder.{nb + 2}", 1, cur, 7, "0.5")
+    ks += conv(f"decoder.{nb + 2}", 1, cur, 7, "0.08")
     return ks
 
 
