@@ -266,14 +266,18 @@ void orc_randn_vectorized(uint32_t seed, int n, float* out) {
     MT19937 r(seed);
     randn_vectorized(r, out, n);
 }
-// processors: which = 0 rep-penalty (arg = penalty, hist), 1 temperature, 2 top-k, 3 top-p
+// processors: which = 0 rep-penalty (arg = penalty, hist), 1 temperature, 2 top-k, 3 top-p,
+// 4 suppress (hist = ids to suppress; apply_suppress_tokens, sampling.rs:143-170)
 void orc_processor(int which, float* logits, int n, double arg, const int64_t* hist, int n_hist) {
     std::vector<float> l(logits, logits + n);
     std::vector<int64_t> hv(hist, hist + n_hist);
     if (which == 0) apply_repetition_penalty(l, hv, arg);
     else if (which == 1) apply_temperature(l, arg);
     else if (which == 2) apply_top_k(l, (int)arg);
-    else apply_top_p(l, arg);
+    else if (which == 4) {
+        for (int64_t id : hv)
+            if (id >= 0 && id < n) l[(size_t)id] = -INFINITY;
+    } else apply_top_p(l, arg);
     std::memcpy(logits, l.data(), sizeof(float) * (size_t)n);
 }
 int64_t orc_sample_token(const float* logits, int n, const double* sampling, const int64_t* hist, int n_hist, uint32_t seed) {
@@ -297,6 +301,33 @@ void orc_mel_filterbank(int n_fft, int num_mels, int sr, double fmin, double fma
     std::vector<float> fb;
     mel_filterbank(n_fft, num_mels, sr, fmin, fmax, fb);
     std::memcpy(out, fb.data(), sizeof(float) * fb.size());
+}
+// rotate_half (nn/rope/mod.rs:64-76): [-x2, x1] over the two halves of the last dimension
+void orc_rotate_half(const float* x, int n, float* out) {
+    const int half = n / 2;
+    for (int i = 0; i < half; ++i) {
+        out[i] = -x[i + half];
+        out[i + half] = x[i];
+    }
+}
+// create_position_ids_with_padding (nn/generation_utils.rs:132-153): max(0, i - pad_len) per row
+void orc_position_ids_with_padding(const int* lengths, int n, int max_len, int64_t* out) {
+    for (int b = 0; b < n; ++b) {
+        const int pad = max_len - lengths[b];
+        for (int i = 0; i < max_len; ++i) out[(size_t)b * max_len + i] = std::max(0, i - pad);
+    }
+}
+// create_attention_mask_from_lengths (nn/generation_utils.rs:63-121): 0 where causal and both positions are
+// non-padding, -inf elsewhere; rows of padding queries are fully masked
+void orc_attention_mask_from_lengths(const int* lengths, int n, int max_len, float* out) {
+    for (int b = 0; b < n; ++b) {
+        const int pad = max_len - lengths[b];
+        for (int i = 0; i < max_len; ++i)
+            for (int j = 0; j < max_len; ++j) {
+                const bool ok = i >= j && i >= pad && j >= pad;
+                out[((size_t)b * max_len + i) * max_len + j] = ok ? 0.0f : -INFINITY;
+            }
+    }
 }
 void orc_linear(const float* x, const float* w, const float* b, float* y, int64_t M, int64_t N, int64_t K) { linear(x, w, b, y, M, N, K); }
 void orc_rmsnorm(const float* x, const float* w, float* y, int64_t rows, int64_t n, float eps) { rmsnorm(x, w, y, rows, n, eps); }

@@ -311,11 +311,13 @@ void Model::embed_and_project_text(const uint32_t* ids, int n, float* out) const
 
 void Model::sum_code_embeddings(const uint32_t* codes, float* out) const {
     const int H = cfg.talker.hidden;
+    if ((int64_t)codes[0] >= W(w, "talker.model.codec_embedding.weight").dim(0)) throw std::runtime_error("oracle: code id out of range");
     const float* e0 = W(w, "talker.model.codec_embedding.weight").p() + (size_t)codes[0] * H;
     for (int i = 0; i < H; ++i) out[i] = e0[i];
     for (int g = 1; g < cfg.groups; ++g) {
-        const float* e = W(w, "talker.code_predictor.model.codec_embedding." + std::to_string(g - 1) + ".weight").p() +
-                         (size_t)codes[g] * H;
+        const Tensor& tab = W(w, "talker.code_predictor.model.codec_embedding." + std::to_string(g - 1) + ".weight");
+        if ((int64_t)codes[g] >= tab.dim(0)) throw std::runtime_error("oracle: code id out of range");
+        const float* e = tab.p() + (size_t)codes[g] * H;
         for (int i = 0; i < H; ++i) out[i] = out[i] + e[i];
     }
 }

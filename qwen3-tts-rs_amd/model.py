@@ -163,6 +163,8 @@ class Model:
             if t.dtype not in (torch.bfloat16, torch.float32):
                 raise QttsError(-1, "device tensors must be f32 or bf16")
             shape = (C.c_int64 * t.dim())(*t.shape)
+            # the library copies on its own stream: the producer of `t` (torch's current stream) must be done first
+            torch.cuda.current_stream(t.device).synchronize()
             check(self.lib.qtts_model_load_tensor_device(self._m, key.encode(), C.c_void_p(t.data_ptr()), src, shape, t.dim()))
             return
         a = np.ascontiguousarray(arr)
