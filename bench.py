@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-seconds generated per wall-second.
+
+Workload (one "step"): batch of synthetic utterances per GPU through the whole hot path of the 1.7B-like shape set
+(prompt -> talker decode -> code predictor -> sampling for `--frames` frames, then the codec decoder to 24 kHz
+waveforms on the host).  Weights are random-init of that architecture, texts are synthetic token ids.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Every rank holds a full weight replica and decodes its own utterances (no collective on the data path); rank 0 prints
+one JSON line.  The CPU oracle is timed on a bounded sample as a reported baseline (rank 0, N = 1 only)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0         # MI355X HBM3E
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 matrix
+FRAME_SECONDS = 0.08          # 12.5 Hz codec frames
+SEED = 20261111
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--shape", default="S17")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
+    ap.add_argument("--frames", type=int, default=375, help="frames generated per utterance (30 s of audio)")
+    ap.add_argument("--greedy", action="store_true", help="CLI --greedy semantics instead of seeded sampling")
+    ap.add_argument("--no-codec", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=96)
+    return ap.parse_args()
+
+
+def build_model(args, device):
+    import torch
+    from qwen3_tts_rs_amd import LoaderConfig, Model, synth
+    cfg, ccfg, tmpl = synth.shape_set(args.shape)
+    m = Model(cfg, None if args.no_codec else ccfg, LoaderConfig(dtype=args.dtype, device=device))
+    keys = synth.talker_keys(cfg) + ([] if args.no_codec else synth.codec_keys(ccfg))
+    for k, t in synth.iter_weights_torch(keys, SEED, f"cuda:{device}", args.dtype == "bf16"):
+        m.load_tensor(k, t)
+        del t
+    m.finalize()
+    torch.cuda.empty_cache()
+    return m, cfg, ccfg, tmpl
+
+
+def make_requests(args, tmpl, rank):
+    from qwen3_tts_rs_amd import GenerationRequest, synth
+    reqs = []
+    for b in range(args.batch):
+        u = rank * args.batch + b                      # global utterance index
+        n = 8 + (u * 37 + 11) % 57                     # text content length in [8, 64]
+        reqs.append(GenerationRequest(text_ids=synth.synthetic_text_ids(tmpl, n, u), language="english", speaker="speaker1",
+                                      seed=None if args.greedy else 42 + u))
+    return reqs
+
+
+def cpu_baseline(args, cfg, ccfg, tmpl):
+    """The CPU oracle (a port of the reference's algorithm, f32, OpenMP over the host cores) on a bounded sample of the
+    same workload: one utterance, a few frames, plus the codec decode of those frames."""
+    import torch
+    from oracle import bind
+    from qwen3_tts_rs_amd import synth
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    o = bind.Oracle(fast=True)
+    keys = synth.talker_keys(cfg) + ([] if args.no_codec else synth.codec_keys(ccfg))
+    for k, t in synth.iter_weights_torch(keys, SEED, "cuda:0", False):
+        o.load_tensor(k, t.float().cpu().numpy())
+        del t
+    o.set_model_config(cfg)
+    if not args.no_codec:
+        o.set_codec_config(ccfg)
+    text = synth.synthetic_text_ids(tmpl, 12, 0)
+    samp = dict(do_sample=False, subtalker_do_sample=False, temperature=1.0, top_k=50, top_p=1.0, repetition_penalty=1.05)
+    t0 = time.perf_counter()
+    r = o.generate(text, bind.resolve_codec_prefill(cfg, "english", "speaker1"), samp, args.cpu_frames,
+                   speaker_token=bind.resolve_speaker_token(cfg, "speaker1"))
+    t1 = time.perf_counter()
+    n = r["effective_len"]
+    if not args.no_codec and n > 0:
+        o.codec_decode(r["codes"][:n, :ccfg["decoder_config"]["num_quantizers"]])
+    t2 = time.perf_counter()
+    audio_s = n * FRAME_SECONDS
+    return {"value": audio_s / (t2 - t0), "unit": "audio_s/s", "cores": threads, "kind": "port",
+            "sample": f"1 utterance (12 text tokens), {n} frames greedy + codec decode of those frames, f32, "
+                      f"generate {t1 - t0:.2f} s, codec {t2 - t1:.2f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+
+    from qwen3_tts_rs_amd import SamplingConfig, synth
+    m, cfg, ccfg, tmpl = build_model(args, local)
+    reqs = make_requests(args, tmpl, rank)
+    sampling = SamplingConfig.cli_greedy() if args.greedy else SamplingConfig()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    stats = dict(prefill_ms=0.0, frames_ms=0.0, frames=0, codec_ms=0.0, audio_s=0.0)
+
+    def step(record):
+        out = m.generate(reqs, sampling, args.frames, use_graph=True)
+        wavs = [] if args.no_codec else m.decode_output(out)
+        if record:
+            stats["prefill_ms"] += m.last_timing["prefill_ms"]
+            stats["frames_ms"] += m.last_timing["frames_ms"]
+            stats["frames"] += m.last_timing["frames"]
+            stats["codec_ms"] += 0.0 if args.no_codec else m.codec_device_ms()
+            stats["audio_s"] += sum(out.effective_lengths) * FRAME_SECONDS
+        return out, wavs
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, wavs = step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # whole-job aggregate: audio seconds of all ranks / slowest rank's time
+    tt = torch.tensor([elapsed, stats["audio_s"]], dtype=torch.float64, device=f"cuda:{local}")
+    if world > 1:
+        mx = tt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tt.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed_max, audio_total = float(mx[0]), float(sm[1])
+    else:
+        elapsed_max, audio_total = elapsed, stats["audio_s"]
+
+    result = None
+    if rank == 0:
+        es = 2 if args.dtype == "bf16" else 4
+        frames_run = max(stats["frames"] - args.steps, 1)       # the first frame of each call comes out of the prefill
+        ms_per_frame = stats["frames_ms"] / frames_run
+        avg_ctx = 40 + args.frames / 2.0                          # mean prompt (~40 positions) + half the generated frames
+        bytes_frame = synth.decode_bytes_per_frame(cfg, args.batch, avg_ctx, es)
+        achieved = bytes_frame / (ms_per_frame * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "decode frame (one hipGraph launch: talker step + code-predictor passes + sampling)",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": None, "bytes_per_launch": bytes_frame, "avg_launch_ms": round(ms_per_frame, 4),
+                    "weight_bytes_per_launch": synth.weight_bytes_per_frame(cfg, es)["total"]}
+        # dominant weight-streaming GEMM, timed launch by launch with HIP events in an eager pass after the timed region
+        m.generate(reqs, sampling, 9, use_graph=False, profile_gemm=True)
+        prof = [p for p in m.gemm_profile() if p["M"] == args.batch]
+        gemm = None
+        if prof:
+            top = max(prof, key=lambda p: p["total_us"])
+            avg_us = top["total_us"] / top["launches"]
+            b2b = m.bench_gemm(top["M"], top["N"], top["K"], 100)
+            wbytes = top["N"] * top["K"] * es
+            gemm = {"bound": "hbm", "kernel": f"skinny GEMM M={top['M']} N={top['N']} K={top['K']} ({args.dtype})",
+                    "achieved": round(wbytes / (b2b * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(wbytes / (b2b * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": wbytes,
+                    "avg_launch_us_back_to_back": round(b2b, 2), "avg_launch_us_in_frame_events": round(avg_us, 2),
+                    "share_of_gemm_time": round(top["total_us"] / sum(p["total_us"] for p in m.gemm_profile()), 3)}
+        codec = None
+        if not args.no_codec and stats["codec_ms"] > 0:
+            fl = synth.codec_flops_per_frame(ccfg) * (stats["audio_s"] / FRAME_SECONDS)
+            peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+            ach = fl / (stats["codec_ms"] * 1e-3) / 1e12
+            codec = {"bound": "mfma", "kernel": "codec decoder (conv / transposed-conv GEMMs + epilogues)", "achieved": round(ach, 2),
+                     "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                     "device_ms_per_step": round(stats["codec_ms"] / args.steps, 2)}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline(args, cfg, ccfg, tmpl)
+            except Exception as e:  # the baseline is a reported figure, not part of the product path
+                cpu = {"value": None, "unit": "audio_s/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        ms_step = elapsed_max / args.steps * 1e3
+        result = {
+            "metric": "audio-sec generated/sec", "value": round(audio_total / elapsed_max, 2), "unit": "audio_s/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.shape} CustomVoice-shaped random-init model, batch {args.batch} synthetic texts per GPU, "
+                                   f"{args.frames} frames each ({'greedy' if args.greedy else 'seeded sampling'}), codec decode "
+                                   f"{'off' if args.no_codec else 'to 24 kHz waveforms on the host'}",
+                       "batch_per_gpu": args.batch, "frames": args.frames, "parallelism": f"dp{world} (per-utterance)"},
+            "p50_first_audio_ms": round(ms_step, 1),   # non-streaming path: audio exists once the whole step is done
+            "phase_ms_per_step": {"prefill": round(stats["prefill_ms"] / args.steps, 2), "frames": round(stats["frames_ms"] / args.steps, 2),
+                                  "codec_device": round(stats["codec_ms"] / args.steps, 2)},
+            "ms_per_frame": round(ms_per_frame, 4),
+            "roofline": roofline, "roofline_gemm": gemm, "roofline_codec": codec, "cpu_baseline": cpu,
+        }
+    m.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

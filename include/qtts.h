@@ -117,8 +117,20 @@ int qtts_generate_ex(qtts_model* m, const qtts_request* reqs, int n, const qtts_
 
 /* Timing of the last qtts_generate_ex call (milliseconds, HIP events on the context stream):
  * out[0] prompt+prefill, out[1] frame loop, out[2] summed GEMM kernel time (profile_gemm only),
- * out[3] GEMM launches timed, out[4] algorithmic weight bytes those launches streamed. */
+ * out[3] GEMM launches timed, out[4] algorithmic weight bytes those launches streamed, out[5] frames run,
+ * out[6] device time of the last qtts_codec_decode call excluding the waveform copy to the host. */
 int qtts_last_timing(qtts_model* m, double* out, int n);
+
+/* Measurement hooks (no counterpart in the reference; used by the benchmark to report rooflines).
+ * qtts_gemm_profile: per-shape totals of the last profile_gemm run, rows of 5 doubles
+ *   (M tokens, N, K, launches, total microseconds); *n_rows receives the number of shapes.
+ * qtts_bench_gemm: average duration (us, HIP events around `iters` back-to-back launches on the context stream)
+ *   of the weight-streaming GEMM out[M][N] = X[M][K] W[N][K]^T, rotating over weight copies so that launches do
+ *   not hit the Infinity Cache; KS <= 0 picks the split-K factor the decode path would use.
+ * qtts_bench_stream: same for a pure read of `bytes` bytes (pattern 0 contiguous, 1 row-tiled). */
+int qtts_gemm_profile(qtts_model* m, double* rows, int cap_rows, int* n_rows);
+int qtts_bench_gemm(qtts_ctx* ctx, int dtype, int M, int N, int K, int KS, int iters, double* avg_us);
+int qtts_bench_stream(qtts_ctx* ctx, long bytes, int blocks, int pattern, int unroll, int ld_bytes, int iters, double* avg_us);
 
 /* Model::decode_output / TokenizerV2::{decode,chunked_decode} (model/generate.rs:29-143,
  * audio/tokenizer/v2/mod.rs:208-232, audio/decoder/v2.rs:163-286).  codes [B][T_max][Q]; lens[b] frames

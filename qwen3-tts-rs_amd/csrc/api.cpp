@@ -127,6 +127,16 @@ int qtts_last_timing(qtts_model* m, double* out, int n) {
     QTTS_API_END
 }
 
+int qtts_gemm_profile(qtts_model* m, double* rows, int cap_rows, int* n_rows) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(m && rows && n_rows && cap_rows >= 0, ERR_BAD_ARG, "qtts_gemm_profile: null argument");
+    const int n = (int)(m->m.gemm_profile.size() / 5);
+    *n_rows = n;
+    for (int i = 0; i < n && i < cap_rows; ++i)
+        for (int j = 0; j < 5; ++j) rows[i * 5 + j] = m->m.gemm_profile[(size_t)i * 5 + j];
+    QTTS_API_END
+}
+
 int qtts_codec_decode(qtts_model* m, const uint32_t* codes, const int* lens, int B, int T_max, int chunk, int left_ctx,
                       float* wav_out, int64_t wav_stride, int64_t* wav_lens) {
     QTTS_API_BEGIN

@@ -438,6 +438,10 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
     s.acc.ensure(g.acc_elems * 4);
     s.wav.ensure((size_t)U * (size_t)g.wav_max * 4);
 
+    hipEvent_t ev0, ev1;
+    QTTS_HIP(hipEventCreate(&ev0));
+    QTTS_HIP(hipEventCreate(&ev1));
+    QTTS_HIP(hipEventRecord(ev0, st));
     // ================= stage 0: RVQ lookup -> pre_conv -> transformer =================
     const long M0 = U * S[0];
     const int Hd = c.hidden;
@@ -628,6 +632,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
     const int last = nstage - 1;
     launch_final_conv(st, dt, s.A.p, s.final_w.as<float>(), s.final_b, d_len(last), U, g.Tmax[(size_t)last], S[(size_t)last], P[(size_t)last],
                       s.final_CP, s.wav.as<float>(), g.wav_max);
+    QTTS_HIP(hipEventRecord(ev1, st));
     const long up_total = c.total_upsample();
     for (int u = 0; u < U; ++u) {
         const Piece& p = ps[(size_t)u];
@@ -639,6 +644,11 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
                                     (size_t)n * 4, hipMemcpyDeviceToHost, st));
     }
     QTTS_HIP(hipStreamSynchronize(st));
+    float ms = 0;
+    QTTS_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+    m.timing[6] += ms;
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
 }
 
 }  // namespace
@@ -694,6 +704,7 @@ void run_codec_decode(Model& m, const uint32_t* codes, const int* lens, int B, i
         }
         QTTS_CHECK(wav_lens[b] <= wav_stride, ERR_SHAPE, "codec decode: wav_stride too small for the decoded length");
     }
+    m.timing[6] = 0;
     if (pieces.empty()) return;
     std::stable_sort(pieces.begin(), pieces.end(), [](const Piece& a, const Piece& b) { return a.len > b.len; });
     s.codes.ensure((size_t)B * T_max * s.Q * 4);

@@ -99,6 +99,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     g.timer.enabled = dbg && dbg->profile_gemm && !use_graph;
     g.timer.used = 0;
     g.timer.bytes = 0;
+    g.timer.shape.clear();
 
     // ------------------------------------------------------------------ host-side prompt planning
     std::vector<int> text_ids = {c.tts_bos, c.tts_eos, c.tts_pad};  // rows 0,1,2 of the projected-text buffer
@@ -515,6 +516,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     m.timing[3] = (double)(g.timer.used / 2);
     m.timing[4] = g.timer.bytes;
     m.timing[5] = (double)steps_done;
+    m.gemm_profile = g.timer.by_shape();
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
     (void)hipEventDestroy(ev2);

@@ -135,6 +135,7 @@ struct Model {
     std::shared_ptr<CodecState> codec_state;
     std::shared_ptr<SpeakerState> spk_state;
     double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<double> gemm_profile;      // rows of (M, N, K, launches, total us) from the last profiled generate
 
     Model();
     ~Model();

@@ -15,10 +15,27 @@ struct Workspace {
 struct GemmTimer {
     bool enabled = false;
     std::vector<hipEvent_t> ev;
+    std::vector<int> shape;  // (M, N, K) per timed launch
     size_t used = 0;
     double bytes = 0;
     ~GemmTimer() {
         for (auto e : ev) (void)hipEventDestroy(e);
+    }
+    // per-shape totals: rows of (M, N, K, launches, total microseconds)
+    std::vector<double> by_shape() const {
+        std::vector<double> rows;
+        for (size_t i = 0; i + 1 < used; i += 2) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, ev[i], ev[i + 1]) != hipSuccess) continue;
+            const int* sh = &shape[(i / 2) * 3];
+            size_t r = 0;
+            for (; r < rows.size(); r += 5)
+                if (rows[r] == sh[0] && rows[r + 1] == sh[1] && rows[r + 2] == sh[2]) break;
+            if (r == rows.size()) rows.insert(rows.end(), {(double)sh[0], (double)sh[1], (double)sh[2], 0.0, 0.0});
+            rows[r + 3] += 1.0;
+            rows[r + 4] += (double)t * 1e3;
+        }
+        return rows;
     }
     double total_ms() const {
         double ms = 0;
@@ -65,6 +82,9 @@ struct Runner {
             QTTS_HIP(hipEventRecord(timer->ev[timer->used + 1], st));
             timer->used += 2;
             timer->bytes += (double)N * K * es;
+            timer->shape.push_back(M);
+            timer->shape.push_back(N);
+            timer->shape.push_back(K);
         }
     }
 

@@ -282,6 +282,26 @@ class Model:
             out.hidden = hidden[:, :steps]
         return out
 
+    def gemm_profile(self):
+        """Per-shape GEMM totals of the last generate(..., use_graph=False, profile_gemm=True):
+        list of dicts (M, N, K, launches, total_us)."""
+        rows = (C.c_double * (5 * 64))()
+        n = C.c_int(0)
+        check(self.lib.qtts_gemm_profile(self._m, rows, 64, C.byref(n)))
+        return [dict(M=int(rows[5 * i]), N=int(rows[5 * i + 1]), K=int(rows[5 * i + 2]), launches=int(rows[5 * i + 3]),
+                     total_us=rows[5 * i + 4]) for i in range(min(n.value, 64))]
+
+    def bench_gemm(self, M: int, N: int, K: int, iters: int = 50) -> float:
+        """Average microseconds of the decode path's weight-streaming GEMM for one shape (back-to-back launches)."""
+        us = C.c_double(0)
+        check(self.lib.qtts_bench_gemm(self._ctx, self.dtype, M, N, K, 0, iters, C.byref(us)))
+        return us.value
+
+    def codec_device_ms(self) -> float:
+        tm = (C.c_double * 8)()
+        check(self.lib.qtts_last_timing(self._m, tm, 8))
+        return tm[6]
+
     def decode_codes(self, codes: np.ndarray, lens: Optional[Sequence[int]] = None, chunk: int = 0, left_ctx: int = 0):
         """TokenizerV2::decode / chunked_decode on (batch, steps, quantizers) codes; returns a list of waveforms."""
         c = np.ascontiguousarray(codes, np.uint32)

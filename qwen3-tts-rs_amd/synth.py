@@ -339,6 +339,45 @@ def weight_bytes_per_frame(cfg, bytes_per_elem: int = 2) -> dict:
                 kv_per_token=2 * L * nkv * d * bytes_per_elem)
 
 
+def decode_bytes_per_frame(cfg, batch: int, ctx: float, bytes_per_elem: int = 2) -> float:
+    """Algorithmic HBM bytes of one decode frame for the whole batch: every weight once, each row's KV cache read
+    and appended once (talker at context `ctx`; code predictor contexts up to G), the G embedding rows per utterance."""
+    t = cfg["talker_config"]
+    c = t["code_predictor_config"]
+    w = weight_bytes_per_frame(cfg, bytes_per_elem)
+    G, H = t["num_code_groups"], t["hidden_size"]
+    kv_t = w["kv_per_token"] * (ctx + 1)
+    kv_c = c["num_hidden_layers"] * c["num_key_value_heads"] * c["head_dim"] * G * (G - 1) * bytes_per_elem
+    return float(w["total"] + batch * (kv_t + kv_c + bytes_per_elem * G * H))
+
+
+def codec_flops_per_frame(codec_cfg) -> float:
+    """Algorithmic FLOPs (2 per multiply-add, GEMM/conv terms only) the codec decoder spends per 12.5 Hz frame."""
+    c = codec_cfg["decoder_config"]
+    Dc, Dl, Hd, Dd, I = c["codebook_dim"], c["latent_dim"], c["hidden_size"], c["decoder_dim"], c["intermediate_size"]
+    nh, nkv = c["num_attention_heads"], c["num_key_value_heads"]
+    d = c.get("head_dim") or Hd // nh
+    f = 2.0 * 3 * Dc * Dl                                   # pre_conv k=3
+    f += 2.0 * (Dl * Hd + Hd * Dl)                          # input / output projections
+    per_layer = 2.0 * (Hd * (nh + 2 * nkv) * d + nh * d * Hd + 3 * Hd * I) + 4.0 * nh * d * min(c["sliding_window"], 72)
+    f += c["num_hidden_layers"] * per_layer
+    rate = 1
+    for r in c["upsampling_ratios"]:
+        f += rate * 2.0 * Dl * Dl * r                       # transposed conv, kernel == stride
+        rate *= r
+        f += rate * (2.0 * 7 * Dl + 2.0 * 2 * Dl * 4 * Dl)  # ConvNeXt: depthwise k=7 + two pointwise layers
+    f += rate * 2.0 * 7 * Dl * Dd                           # decoder.0 k=7
+    cur = Dd
+    for r in c["upsample_rates"]:
+        nxt = cur // 2
+        f += rate * 2.0 * cur * nxt * 2 * r                 # transposed conv k = 2r (per input step)
+        rate *= r
+        f += rate * 3 * (2.0 * 7 * nxt * nxt + 2.0 * nxt * nxt)
+        cur = nxt
+    f += rate * 2.0 * 7 * cur
+    return f
+
+
 def iter_weights_torch(keys, seed: int, device="cuda", bf16: bool = False):
     """Random-init weights generated on the GPU with torch (benchmarks only: fast, but not the bit-exact
     counter-based stream of iter_weights).  Yields (key, tensor); matrices are bf16 when `bf16`."""
