@@ -61,12 +61,18 @@ __global__ __launch_bounds__(256) void conv_epilogue_kernel(ConvEpi e) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float x = v[q] + (e.bias ? e.bias[co + q] : 0.f);
+            if (e.bias_u) x += e.bias_u[u * e.Cout + co + q];
             if (e.act == 1) x = gelu_tanh(x);
+            else if (e.act >= 2) {
+                x = fmaxf(x, 0.f);
+                if (e.act == 3) x = tanhf(x);
+            }
             if (e.scale) x = x * e.scale[co + q];
             if (e.resid) x = to_f32<T>(((const T*)e.resid)[orow * e.ld_out + co + q]) + x;
             if (e.resid_f32) x = e.resid_f32[orow * e.ld_out + co + q] + x;
             v[q] = x;
         }
+        if (e.Cvalid && co >= e.Cvalid) continue;  // columns past the layer's real width are padding
         if (e.out) {
             T* o = (T*)e.out + orow * e.ld_out + co;
 #pragma unroll
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_epilogue_kernel(ConvEpi e) {
 }
 
 void launch_conv_epilogue(hipStream_t st, int dtype, const ConvEpi& e) {
-    QTTS_CHECK(e.N % 4 == 0 && e.Cout % 4 == 0 && e.N == e.r * e.Cout && e.M >= 1, ERR_SHAPE, "conv_epilogue: bad shape");
+    QTTS_CHECK(e.N % 4 == 0 && e.Cout % 4 == 0 && e.N == e.r * e.Cout && e.M >= 1 && e.Cvalid % 4 == 0, ERR_SHAPE, "conv_epilogue: bad shape");
     QTTS_CHECK(e.out2 == nullptr || (e.alpha_exp && e.beta_den), ERR_BAD_ARG, "conv_epilogue: snake output without parameters");
     const long total = e.M * (long)e.N / 4;
     const int blocks = (int)std::min<long>((total + 255) / 256, 8192);

@@ -130,8 +130,10 @@ struct ConvEpi {
     long M;                  // rows to visit
     int N, r, Cout;          // N = r * Cout (r > 1: transposed conv folded into N)
     const float* bias;       // [Cout] or null
+    const float* bias_u;     // [U][Cout] or null: extra per-strip bias
+    int Cvalid;              // 0: write all Cout columns; otherwise only columns < Cvalid (multiple of 4)
     const float* scale;      // [Cout] or null (ConvNeXt gamma)
-    int act;                 // 0 none, 1 tanh-GELU
+    int act;                 // 0 none, 1 tanh-GELU, 2 ReLU, 3 tanh(ReLU)
     const int* lens;         // [U] valid GEMM rows per strip
     long S_in, S_out;        // strip lengths (rows) of the GEMM row space / of the output tensor
     int P_out, ld_out;       // output row = u * S_out + P_out + t' * r + j ; ld_out = channel stride of out / out2 / resid
@@ -150,5 +152,20 @@ void launch_dwconv_ln(hipStream_t st, int dtype, const void* x, const float* w, 
                       const int* lens, int U, int Tmax, long S, int P, int C, void* out);
 void launch_final_conv(hipStream_t st, int dtype, const void* x, const float* w, float bias, const int* nvalid, int U, long Tmax, long S,
                        int P, int C, float* wav, long wav_stride);
+
+// ---- k_speaker.hip
+void launch_mel(hipStream_t st, int dtype, const float* audio, const int* n_samples, int B, int max_samples, int max_frames,
+                const float* window, const float* twiddle, const float* fbT, float* mel_out, long frames_stride, void* strips, long S,
+                int P);
+void launch_reflect_fill(hipStream_t st, int dtype, void* x, const int* lens, int U, long S, int P, int pad, int C);
+void launch_res2net_prep(hipStream_t st, int dtype, const void* a, const void* prev, const int* lens, int U, int Tmax, long S, int P,
+                         int pad, int ld, int off, int cs, void* tmp);
+void launch_slice_copy(hipStream_t st, int dtype, const void* a, const int* lens, int U, int Tmax, long S, int P, int ld, int cs, void* out);
+void launch_time_stats(hipStream_t st, int dtype, const void* x, int ldx, const float* logits, int ldl, const float* lbias, const int* lens,
+                       int U, long S, int P, int Pl, int C, int mode, float* out);  // Pl: leading rows of the logits' row space
+void launch_small_fc(hipStream_t st, const float* W, int ldw, const float* b, const float* x, int ldx, int U, int N, int K, int act, float* y,
+                     int ldy);
+void launch_se_apply(hipStream_t st, int dtype, const void* x, int ldx, const float* gate, const void* resid, int ldr, const int* lens, int U,
+                     int Tmax, long S, int P, int C, void* out, int ldo);
 
 }  // namespace qtts
