@@ -75,6 +75,7 @@ struct GenState {
     StackRun talker, cp;
     size_t cap_rows = 0;
     GemmTimer timer;                         // optional HIP-event timing of every GEMM launch
+    DevBuf icl;                              // reference code ids + destination rows of ICL prompts
     hipGraphExec_t graph_exec = nullptr;
     ~GenState() {
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -113,10 +114,12 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     std::vector<int> row_P(B), trail_len(B, 0);
     std::vector<std::vector<int>> trail_idx((size_t)B);
     std::vector<float> extra_rows;
+    std::vector<int> icl_codes, icl_rows;  // reference frames whose embedding sums are computed on the device
     for (int b = 0; b < B; ++b) {
         const qtts_request& r = reqs[b];
         QTTS_CHECK(r.text_ids && r.n_text >= 4, ERR_BAD_ARG, "generate: text_ids needs at least 4 tokens");
-        QTTS_CHECK(r.ref_T == 0 && r.ref_codes == nullptr, ERR_BAD_ARG, "generate: ICL reference codes are not supported yet");
+        const bool icl = r.ref_codes != nullptr && r.ref_T > 0 && r.ref_text_ids != nullptr && r.n_ref_text >= 4;
+        QTTS_CHECK(r.ref_T >= 0 && (r.ref_codes == nullptr) == (r.ref_T == 0), ERR_BAD_ARG, "generate: ref_codes and ref_T disagree");
         // build_codec_prefill (generation.rs:452-498)
         std::string lang = lower(r.language ? r.language : "auto");
         const std::string spk = lower(r.speaker);
@@ -153,7 +156,40 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
             codec_part(i, cd, ex);
             push(i < L - 2 ? 2 : 0, cd, ex);
         }
-        if (r.non_streaming && r.n_text > 8) {
+        if (icl) {
+            // generate_icl_prompt (generation.rs:292-416, 629-696): text side = ref text (3..-2) || text (3..-5) || tts_eos,
+            // codec side = bos || per-frame sums of the reference codes over all codebooks
+            std::vector<int> te;
+            const int rte = r.n_ref_text >= 2 ? r.n_ref_text - 2 : 0;
+            for (int i = 3; i < (rte > 3 ? rte : 4); ++i) te.push_back(add_text(r.ref_text_ids[i]));
+            const int tce = r.n_text >= 5 ? r.n_text - 5 : 0;
+            for (int i = 3; i < (tce > 3 ? tce : 4); ++i) te.push_back(add_text(r.text_ids[i]));
+            te.push_back(1);
+            const int text_lens = (int)te.size(), codec_lens = r.ref_T + 1;
+            const int icl_row0 = (int)(extra_rows.size() / (size_t)H);
+            extra_rows.resize(extra_rows.size() + (size_t)r.ref_T * H, 0.f);
+            for (int t = 0; t < r.ref_T; ++t) {
+                for (int gi = 0; gi < G; ++gi) {
+                    const uint32_t code = r.ref_codes[(size_t)t * G + gi];
+                    QTTS_CHECK((int)code < (gi == 0 ? V : Vc), ERR_BAD_ARG, "generate: reference code id out of range");
+                    icl_codes.push_back((int)code);
+                }
+                icl_rows.push_back(icl_row0 + t);
+            }
+            auto ce = [&](int i, int& cd, int& ex) {
+                if (i == 0) { cd = c.bos; ex = -1; }
+                else { cd = -1; ex = icl_row0 + i - 1; }
+            };
+            if (r.non_streaming) {
+                for (int i = 0; i < text_lens; ++i) push(te[(size_t)i], c.pad, -1);
+                for (int i = 0; i < codec_lens; ++i) { int cd, ex; ce(i, cd, ex); push(2, cd, ex); }
+            } else if (text_lens > codec_lens) {
+                for (int i = 0; i < codec_lens; ++i) { int cd, ex; ce(i, cd, ex); push(te[(size_t)i], cd, ex); }
+                for (int i = codec_lens; i < text_lens; ++i) trail_idx[(size_t)b].push_back(te[(size_t)i]);
+            } else {
+                for (int i = 0; i < codec_lens; ++i) { int cd, ex; ce(i, cd, ex); push(i < text_lens ? te[(size_t)i] : 2, cd, ex); }
+            }
+        } else if (r.non_streaming && r.n_text > 8) {
             for (int i = 3; i < r.n_text - 5; ++i) push(add_text(r.text_ids[i]), c.pad, -1);
             push(1, c.pad, -1);
             push(2, c.bos, -1);
@@ -290,6 +326,13 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     QTTS_HIP(hipMemcpyAsync(g.trailing_len.p, trail_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     QTTS_HIP(hipMemcpyAsync(g.row_len.p, row_P.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
     if (!extra_rows.empty()) QTTS_HIP(hipMemcpyAsync(g.extra.p, extra_rows.data(), extra_rows.size() * 4, hipMemcpyHostToDevice, st));
+    if (!icl_rows.empty()) {  // sum_ref_code_embeddings (generation.rs:242-273) into the extra rows
+        g.icl.ensure((icl_codes.size() + icl_rows.size()) * 4);
+        QTTS_HIP(hipMemcpyAsync(g.icl.p, icl_codes.data(), icl_codes.size() * 4, hipMemcpyHostToDevice, st));
+        QTTS_HIP(hipMemcpyAsync(g.icl.as<int>() + icl_codes.size(), icl_rows.data(), icl_rows.size() * 4, hipMemcpyHostToDevice, st));
+        launch_sum_code_rows(st, dt, m.codec_emb, (const void* const*)m.cp_emb_ptrs.p, g.icl.as<int>(), g.icl.as<int>() + icl_codes.size(),
+                             (int)icl_rows.size(), G, H, g.extra.as<float>());
+    }
     QTTS_HIP(hipMemsetAsync(g.step.p, 0, 16, st));
     QTTS_HIP(hipMemsetAsync(g.eos_step.p, 0xff, (size_t)B * 4, st));
     QTTS_HIP(hipMemsetAsync(g.hist.p, 0, (size_t)B * V * 4, st));

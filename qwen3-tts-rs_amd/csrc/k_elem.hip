@@ -203,6 +203,28 @@ void launch_embed_sum_norm(hipStream_t st, int dtype, const EmbedSumArgs& a, con
     else throw Error(ERR_BAD_ARG, "embed_sum: embedding and activation dtypes must match");
 }
 
+// sum_ref_code_embeddings (qwen_tts/src/nn/generation.rs:242-273): dst[rows[i]] = codec_emb[c0] + sum_g cp_emb[g-1][c_g]
+// for reference frames of an ICL prompt; adds run in codebook order in f32.
+template <typename TE>
+__global__ __launch_bounds__(256) void sum_code_rows_kernel(const TE* __restrict__ codec_emb, const void* const* cp_emb,
+                                                            const int* __restrict__ codes, const int* __restrict__ rows, int G, int H,
+                                                            float* dst) {
+    const int i = blockIdx.x;
+    const int* c = codes + (long)i * G;
+    float* o = dst + (long)rows[i] * H;
+    for (int h = threadIdx.x; h < H; h += blockDim.x) {
+        float v = to_f32<TE>(codec_emb[(long)c[0] * H + h]);
+        for (int g = 1; g < G; ++g) v = v + to_f32<TE>(((const TE*)cp_emb[g - 1])[(long)c[g] * H + h]);
+        o[h] = v;
+    }
+}
+void launch_sum_code_rows(hipStream_t st, int edtype, const void* codec_emb, const void* const* cp_emb, const int* codes, const int* rows,
+                          int n, int G, int H, float* dst) {
+    QTTS_CHECK(n >= 1 && G >= 1 && H >= 1, ERR_SHAPE, "sum_code_rows: bad shape");
+    if (edtype == BF16) hipLaunchKernelGGL(sum_code_rows_kernel<bf16_t>, dim3(n), dim3(256), 0, st, (const bf16_t*)codec_emb, cp_emb, codes, rows, G, H, dst);
+    else hipLaunchKernelGGL(sum_code_rows_kernel<float>, dim3(n), dim3(256), 0, st, (const float*)codec_emb, cp_emb, codes, rows, G, H, dst);
+}
+
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void gather_codes_kernel(const TS* __restrict__ table, const unsigned* codes_base,
                                                            long row_stride, const int* step, int G, int g, TD* dst, int H) {

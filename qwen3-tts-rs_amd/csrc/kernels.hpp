@@ -75,6 +75,9 @@ void launch_embed_sum_norm(hipStream_t st, int dtype, const EmbedSumArgs& a, con
 // code-predictor input rows: dst[b] = table[codes[b][g]] cast to dtype (codes laid out as in EmbedSumArgs)
 void launch_gather_codes(hipStream_t st, const void* table, int tdtype, const unsigned* codes_base, long row_stride,
                          const int* step, int G, int g, void* dst, int ddtype, int B, int H);
+// ICL prompt rows: dst[rows[i]][:] = codec_emb[codes[i][0]] + sum_g cp_emb[g-1][codes[i][g]]  (f32)
+void launch_sum_code_rows(hipStream_t st, int edtype, const void* codec_emb, const void* const* cp_emb, const int* codes, const int* rows,
+                          int n, int G, int H, float* dst);
 void launch_cast_rows(hipStream_t st, const float* src, void* dst, int ddtype, long n);
 // decode-step bookkeeping (device-side so the frame can live in a hipGraph)
 // toks[b] = {b, row_len[b], window start, ctx}; row_len[b] += 1

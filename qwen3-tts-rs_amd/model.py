@@ -115,6 +115,32 @@ class GenerationResult:  # model/types.rs:53-69
 
 
 @dataclass
+class VoiceClonePromptItem:  # model/voice_clone.rs:64-181 (the transcript arrives tokenised: tokenize_ref_text output)
+    ref_spk_embedding: np.ndarray
+    ref_code: Optional[np.ndarray] = None          # (codes_len, num_quantizers)
+    x_vector_only_mode: bool = True
+    ref_text_ids: Optional[Sequence[int]] = None   # ids of `<|im_start|>assistant\n{ref_text}<|im_end|>\n`
+
+    @classmethod
+    def x_vector_only(cls, ref_spk_embedding):
+        return cls(ref_spk_embedding=ref_spk_embedding)
+
+    @classmethod
+    def icl(cls, ref_code, ref_spk_embedding, ref_text_ids):
+        return cls(ref_spk_embedding=ref_spk_embedding, ref_code=ref_code, x_vector_only_mode=False, ref_text_ids=ref_text_ids)
+
+    def is_icl(self) -> bool:
+        return not self.x_vector_only_mode
+
+    def validate(self):
+        if self.is_icl():
+            if self.ref_code is None:
+                raise QttsError(-5, "ICL mode requires ref_code to be present")
+            if self.ref_text_ids is None:
+                raise QttsError(-5, "ICL mode requires ref_text to be present")
+
+
+@dataclass
 class LoaderConfig:  # model/loader.rs:31-54
     dtype: str = "bf16"
     load_tokenizer: bool = True
@@ -383,16 +409,37 @@ class Model:
                                 non_streaming_mode=o.get("non_streaming_mode", True) is not False, seed=o.get("seed"))
         return self._finish(self.generate([req], sampling, mx), decode)
 
-    def generate_voice_clone_full(self, text_ids, language: str, speaker_embed: np.ndarray, options: dict = None,
+    def generate_voice_clone_full(self, text_ids, language: str, prompt, options: dict = None,
                                   decode: bool = True) -> GenerationResult:
-        """x-vector-only voice clone (model/generate.rs:452-530): the speaker embedding takes one prompt position."""
+        """Voice clone (model/generate.rs:452-644).  `prompt` is a VoiceClonePromptItem (or a bare speaker embedding for
+        x-vector-only mode).  ICL mode feeds the reference codes / transcript into the prompt, decodes
+        [ref_code || generated codes] and cuts floor(ref_len / total_len * n_samples) leading samples."""
         self.validate_language(language)
+        if not isinstance(prompt, VoiceClonePromptItem):
+            prompt = VoiceClonePromptItem.x_vector_only(np.asarray(prompt, np.float32))
+        prompt.validate()
         o = dict(options or {})
         sampling = self.generate_defaults.merge(**o)
         mx = self.generate_defaults.effective_max_tokens(o.get("max_new_tokens"))
-        req = GenerationRequest(text_ids=text_ids, language=language, speaker_embed=speaker_embed,
-                                non_streaming_mode=o.get("non_streaming_mode", True) is not False, seed=o.get("seed"))
-        return self._finish(self.generate([req], sampling, mx), decode)
+        ns = o.get("non_streaming_mode")
+        req = GenerationRequest(text_ids=text_ids, language=language, speaker_embed=prompt.ref_spk_embedding,
+                                ref_codes=prompt.ref_code, ref_text_ids=prompt.ref_text_ids,
+                                non_streaming_mode=(not prompt.x_vector_only_mode) if ns is None else bool(ns), seed=o.get("seed"))
+        out = self.generate([req], sampling, mx)
+        if out.num_steps == 0:
+            raise QttsError(-5, "Generation produced no audio. The model generated 0 steps.")
+        audio = []
+        if decode and self.codec_config is not None:
+            if prompt.ref_code is not None and not prompt.x_vector_only_mode:
+                ref = np.ascontiguousarray(prompt.ref_code, np.uint32)
+                comb = np.concatenate([ref[None], out.codes], axis=1)
+                total = out.effective_lengths[0] + len(ref)
+                full = self.decode_output(Output(codes=comb, num_steps=out.num_steps + len(ref), effective_lengths=[total]))[0]
+                cut = int(len(ref) / total * len(full))
+                audio = [full[cut:]]
+            else:
+                audio = self.decode_output(out)
+        return GenerationResult(audio=audio, sample_rate=self.sample_rate(), codes=out.codes, effective_lengths=out.effective_lengths)
 
     def generate_custom_voice_from_texts_batch(self, text_ids_list, speaker: str, language: str, options: dict = None,
                                                decode: bool = True) -> GenerationResult:

@@ -92,6 +92,31 @@ def test_voice_design_and_xvector_prompts(t0_f32, bind, golden):
     assert np.array_equal(out.codes[0], r0["codes"]) and np.array_equal(out.codes[1], r1["codes"])
 
 
+@pytest.mark.parametrize("non_streaming", [False, True])
+def test_icl_prompt_matches_golden(t0_f32, bind, golden, non_streaming):
+    """Voice clone with in-context reference codes + transcript (generate_icl_prompt, nn/generation.rs:292-416)."""
+    from qwen3_tts_rs_amd import GenerationRequest
+    m, cfg, tmpl = t0_f32
+    req = GenerationRequest(text_ids=golden["text_ids"], language="english", speaker_embed=golden["xvector"],
+                            ref_codes=golden["ref_codes"], ref_text_ids=golden["ref_text_ids"], non_streaming_mode=non_streaming)
+    out = m.generate([req, _req(golden["text_ids"])], _sampling(GREEDY), 24)
+    if not non_streaming:
+        assert np.array_equal(out.codes[0], golden["icl_codes"])
+    o, _, _, _ = make_oracle(bind, "T0", "f32", talker=True, codec=False)
+    r = o.generate(golden["text_ids"], bind.resolve_codec_prefill(cfg, "english", None), GREEDY, 24, speaker_embed=golden["xvector"],
+                   ref_text_ids=golden["ref_text_ids"], ref_codes=golden["ref_codes"], non_streaming=non_streaming)
+    assert np.array_equal(out.codes[0], r["codes"])
+    assert np.array_equal(out.codes[1], golden["greedy_codes"][:24])      # the other row of the batch is unaffected
+    # a short text makes the reference codec side longer than the text side (third layout of generate_icl_prompt)
+    short = golden["text_ids"][[0, 1, 2, 3, -5, -4, -3, -2, -1]]
+    req2 = GenerationRequest(text_ids=short, language="english", speaker_embed=golden["xvector"], ref_codes=golden["ref_codes"],
+                             ref_text_ids=golden["ref_text_ids"][[0, 1, 2, 3, -2, -1]], non_streaming_mode=non_streaming)
+    out2 = m.generate([req2], _sampling(GREEDY), 8)
+    r2 = o.generate(short, bind.resolve_codec_prefill(cfg, "english", None), GREEDY, 8, speaker_embed=golden["xvector"],
+                    ref_text_ids=golden["ref_text_ids"][[0, 1, 2, 3, -2, -1]], ref_codes=golden["ref_codes"], non_streaming=non_streaming)
+    assert np.array_equal(out2.codes[0], r2["codes"])
+
+
 def test_streaming_text_mode(t0_f32, bind, golden):
     """non_streaming_mode = false: the text after the first token is fed one row per generated frame
     (nn/generation.rs:769-789,1096-1106)."""

@@ -116,3 +116,30 @@ def test_full_size_speaker_encoder_properties():
         assert np.abs(e[0] - e[9]).max() > 1e-3
     finally:
         m.close()
+
+
+def test_icl_voice_clone_end_to_end(bind, golden):
+    """ICL voice clone: reference codes + transcript in the prompt, decode of [ref_code || generated], proportional cut of the
+    reference part (model/generate.rs:545-634)."""
+    from conftest import snr_db
+    from golden.make_golden import GREEDY
+    from qwen3_tts_rs_amd import VoiceClonePromptItem, synthetic_model
+    m, cfg, ccfg, tmpl = synthetic_model("T0", dtype="f32", model_type="base", codec=True)
+    ob, _, _, _ = make_oracle(bind, "T0", "f32", model_type="base", talker=True, codec=True)
+    try:
+        emb = m.extract_speaker_embedding([make_audio(20000, 6)])[0]
+        prompt = VoiceClonePromptItem.icl(golden["ref_codes"], emb, golden["ref_text_ids"])
+        res = m.generate_voice_clone_full(golden["text_ids"], "english", prompt,
+                                          options=dict(do_sample=False, subtalker_do_sample=False, temperature=1.0, max_new_tokens=12))
+        r = ob.generate(golden["text_ids"], bind.resolve_codec_prefill(cfg, "english", None), GREEDY, 12, speaker_embed=emb,
+                        ref_text_ids=golden["ref_text_ids"], ref_codes=golden["ref_codes"], non_streaming=True)
+        assert np.array_equal(res.codes[0], r["codes"])
+        comb = np.concatenate([golden["ref_codes"], r["codes"][:r["effective_len"]]])
+        full = ob.codec_decode(comb)
+        cut = int(len(golden["ref_codes"]) / len(comb) * len(full))
+        assert len(res.audio[0]) == len(full) - cut
+        assert snr_db(full[cut:], res.audio[0]) >= 40.0
+        with pytest.raises(Exception, match="ICL mode requires ref_text"):
+            m.generate_voice_clone_full(golden["text_ids"], "english", VoiceClonePromptItem(emb, golden["ref_codes"], False, None))
+    finally:
+        m.close()
