@@ -194,6 +194,59 @@ int qtts_bench_gemm(qtts_ctx* ctx, int dtype, int M, int N, int K, int KS, int i
     QTTS_API_END
 }
 
+// mode 0: `iters` iterations of two grid barriers inside one resident grid of `blocks` x `threads`; avg_us is per barrier and
+// *errors counts visibility failures / aborted waits.  mode 1: a hipGraph of `iters` empty kernels; avg_us per kernel node.
+int qtts_bench_sync(qtts_ctx* ctx, int mode, int blocks, int threads, int iters, double* avg_us, int* errors) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(ctx && avg_us && errors && iters >= 1, ERR_BAD_ARG, "qtts_bench_sync: bad argument");
+    QTTS_HIP(hipSetDevice(ctx->c.device));
+    hipStream_t st = ctx->c.stream;
+    hipEvent_t e0, e1;
+    QTTS_HIP(hipEventCreate(&e0));
+    QTTS_HIP(hipEventCreate(&e1));
+    float ms = 0;
+    *errors = 0;
+    if (mode == 0) {
+        int dev_cus = 0;
+        QTTS_HIP(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->c.device));
+        QTTS_CHECK(blocks <= dev_cus * (threads <= 512 ? 2 : 1), ERR_SHAPE, "qtts_bench_sync: grid would not be co-resident");
+        DevBuf state;
+        state.alloc((size_t)(64 + blocks) * 4 + 1024);
+        for (int rep = 0; rep < 2; ++rep) {  // first run warms up
+            QTTS_HIP(hipMemsetAsync(state.p, 0, (size_t)(64 + blocks) * 4 + 1024, st));
+            QTTS_HIP(hipEventRecord(e0, st));
+            launch_barrier_bench(st, state.as<unsigned>(), blocks, threads, iters);
+            QTTS_HIP(hipEventRecord(e1, st));
+            QTTS_HIP(hipStreamSynchronize(st));
+        }
+        QTTS_HIP(hipEventElapsedTime(&ms, e0, e1));
+        unsigned h[32];
+        QTTS_HIP(hipMemcpy(h, state.p, sizeof(h), hipMemcpyDeviceToHost));
+        *errors = (int)h[17] + (h[16] ? 1000000 : 0);
+        *avg_us = (double)ms * 1e3 / (2.0 * iters);
+    } else {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        QTTS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        for (int i = 0; i < iters; ++i) launch_null(st);
+        QTTS_HIP(hipStreamEndCapture(st, &graph));
+        QTTS_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        QTTS_HIP(hipGraphDestroy(graph));
+        for (int rep = 0; rep < 2; ++rep) {
+            QTTS_HIP(hipEventRecord(e0, st));
+            QTTS_HIP(hipGraphLaunch(exec, st));
+            QTTS_HIP(hipEventRecord(e1, st));
+            QTTS_HIP(hipStreamSynchronize(st));
+        }
+        QTTS_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipGraphExecDestroy(exec);
+        *avg_us = (double)ms * 1e3 / iters;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    QTTS_API_END
+}
+
 int qtts_bench_stream(qtts_ctx* ctx, long bytes, int blocks, int pattern, int unroll, int ld_bytes, int iters, double* avg_us) {
     QTTS_API_BEGIN
     QTTS_HIP(hipSetDevice(ctx->c.device));

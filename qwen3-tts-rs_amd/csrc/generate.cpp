@@ -456,7 +456,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
                 launch_resid_norm(st, dt, nullptr, g.ws.q.as<float>(), 1, 0, nullptr, nullptr, m.cp.layers[0].ln1, c.cp.eps, g.ws.x.as<float>(), g.ws.xn.p,
                                   nullptr, B, Hc);
             }
-            R.stack(m.cp, B, ct + 2 * B + (size_t)j * B, g.cp.kv, g.ws.xn.p, nullptr);
+            R.stack(m.cp, B, ct + 2 * B + (size_t)j * B, g.cp.kv, g.ws.xn.p, nullptr, true, true);
             R.gemm(m.cp_head[(size_t)j], g.ws.xn.p, B, Vc, Hc, 1, Hc);
             sample(g.ws.part.as<float>(), Vc, j + 1, false);
         }
@@ -471,7 +471,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     };
     auto talker_step = [&]() {  // generation.rs:1002-1026
         launch_make_decode_toks(st, g.row_len.as<int>(), g.toks_dec.as<Tok>(), B, c.talker.window);
-        R.stack(m.talker, B, g.toks_dec.as<Tok>(), g.talker.kv, hid_t, hid_f);
+        R.stack(m.talker, B, g.toks_dec.as<Tok>(), g.talker.kv, hid_t, hid_f, true, true);
     };
     auto trace_copy = [&](int step) {
         // logits of this frame are recomputed into the partial buffer by frame_tail; hidden is in hid_f

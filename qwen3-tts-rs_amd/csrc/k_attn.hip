@@ -161,6 +161,169 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Decode-step variant: the token's own q/k/v post-processing (split-K combine, bias, per-head RMSNorm, RoPE, KV
+// append) happens inside the attention block, so one launch replaces qkv_post + attention.  Valid only when a
+// token's newest key is its own position and no other token of the launch attends to it (decode steps, the code
+// predictor's single-token passes); prefill chunks use the two-kernel path.
+template <typename T, int D, int REP>
+__global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KVView kv, float scale, T* out) {
+    constexpr int LPK = D / 8, KPW = 64 / LPK, HALF = D / 2;
+    __shared__ float sm[4][REP][LPK][10];
+    __shared__ float qs[REP][D];
+    __shared__ float kown[D], vown[D];
+    const int m = blockIdx.x, g = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const Tok t = a.toks[m];
+    const int ncol = (a.nh + 2 * a.nkv) * D;
+    // ---- phase 1: k, v and the REP query heads of this kv group (one wave per head, lane = rotation pair)
+    for (int hh = wave; hh < 2 + REP; hh += 4) {
+        const bool is_k = hh == 0, is_v = hh == 1;
+        const int head = is_k ? a.nh + g : (is_v ? a.nh + a.nkv + g : g * REP + (hh - 2));
+        const bool act = lane < HALF;
+        const int i = act ? lane : 0;
+        const long col = (long)head * D + i;
+        float x1 = 0.f, x2 = 0.f;
+        for (int k = 0; k < a.KS; ++k) {
+            const float* p = a.part + k * a.ks_stride + (long)m * ncol + col;
+            x1 += p[0];
+            x2 += p[HALF];
+        }
+        if (a.bias) {
+            x1 += a.bias[col];
+            x2 += a.bias[col + HALF];
+        }
+        if (!is_v) {
+            const float* nw = is_k ? a.k_norm : a.q_norm;
+            if (nw) {
+                const float ss = wave_sum(act ? x1 * x1 + x2 * x2 : 0.f);
+                const float mm = sqrtf(ss / (float)D + a.eps);
+                x1 = x1 / mm * nw[i];
+                x2 = x2 / mm * nw[i + HALF];
+            }
+            const float c = a.cos[(long)t.pos * HALF + i], s = a.sin[(long)t.pos * HALF + i];
+            const float y1 = x1 * c - x2 * s, y2 = x1 * s + x2 * c;
+            x1 = y1;
+            x2 = y2;
+        }
+        if (act) {
+            if (is_k || is_v) {
+                T* dst = kv_ptr<T>(kv, a.layer, t.row, t.pos, is_k ? 0 : 1, g);
+                const T r1 = from_f32<T>(x1), r2 = from_f32<T>(x2);
+                dst[i] = r1;
+                dst[i + HALF] = r2;
+                float* own = is_k ? kown : vown;
+                own[i] = to_f32<T>(r1);   // the value later steps will read back from the cache
+                own[i + HALF] = to_f32<T>(r2);
+            } else {
+                qs[hh - 2][i] = x1;
+                qs[hh - 2][i + HALF] = x2;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: online-softmax attention; the newest key comes from LDS, the rest from the cache
+    const int gi = lane / LPK, li = lane % LPK;
+    float qv[REP][8], o[REP][8], mx[REP], l[REP];
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qv[h][e] = qs[h][li * 8 + e]; o[h][e] = 0.f; }
+        mx[h] = -1e30f;
+        l[h] = 0.f;
+    }
+    for (int base = wave * KPW; base < t.ctx_len; base += 4 * KPW) {
+        const int key = base + gi;
+        const bool valid = key < t.ctx_len;
+        const bool own = key == t.ctx_len - 1;
+        const int pos = t.ctx_start + (valid ? key : 0);
+        float kf[8], vf[8];
+        if (own) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { kf[e] = kown[li * 8 + e]; vf[e] = vown[li * 8 + e]; }
+        } else {
+            load8(kv_ptr<T>(kv, a.layer, t.row, pos, 0, g) + li * 8, kf);
+            load8(kv_ptr<T>(kv, a.layer, t.row, pos, 1, g) + li * 8, vf);
+        }
+#pragma unroll
+        for (int h = 0; h < REP; ++h) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += qv[h][e] * kf[e];
+#pragma unroll
+            for (int off = LPK / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            s = valid ? s * scale : -INFINITY;
+            const float mn = fmaxf(mx[h], s);
+            const float alpha = expf(mx[h] - mn);
+            const float p = expf(s - mn);
+            l[h] = l[h] * alpha + p;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[h][e] = o[h][e] * alpha + p * vf[e];
+            mx[h] = mn;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+#pragma unroll
+        for (int off = LPK; off < 64; off <<= 1) {
+            const float mo = __shfl_xor(mx[h], off, 64), lo = __shfl_xor(l[h], off, 64);
+            const float mn = fmaxf(mx[h], mo);
+            const float a1 = expf(mx[h] - mn), a2 = expf(mo - mn);
+            l[h] = l[h] * a1 + lo * a2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[h][e] = o[h][e] * a1 + __shfl_xor(o[h][e], off, 64) * a2;
+            mx[h] = mn;
+        }
+        if (gi == 0) {
+            sm[wave][h][li][0] = mx[h];
+            sm[wave][h][li][1] = l[h];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sm[wave][h][li][2 + e] = o[h][e];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < REP * LPK) {
+        const int h = threadIdx.x / LPK, j = threadIdx.x % LPK;
+        float mn = sm[0][h][j][0];
+        for (int w = 1; w < 4; ++w) mn = fmaxf(mn, sm[w][h][j][0]);
+        float lt = 0.f, ot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int w = 0; w < 4; ++w) {
+            const float aw = expf(sm[w][h][j][0] - mn);
+            lt += sm[w][h][j][1] * aw;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ot[e] += sm[w][h][j][2 + e] * aw;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ot[e] = ot[e] / lt;
+        store8(out + ((long)m * a.nh + (long)g * REP + h) * D + j * 8, ot);
+    }
+}
+
+template <typename T, int D>
+static void launch_attn_decode_rep(hipStream_t st, const QkvPostArgs& a, const KVView& kv, float scale, T* out) {
+    const int rep = a.nh / kv.nkv;
+    dim3 grid(a.M, kv.nkv), block(256);
+    switch (rep) {
+        case 1: hipLaunchKernelGGL((attention_decode_kernel<T, D, 1>), grid, block, 0, st, a, kv, scale, out); break;
+        case 2: hipLaunchKernelGGL((attention_decode_kernel<T, D, 2>), grid, block, 0, st, a, kv, scale, out); break;
+        case 4: hipLaunchKernelGGL((attention_decode_kernel<T, D, 4>), grid, block, 0, st, a, kv, scale, out); break;
+        case 8: hipLaunchKernelGGL((attention_decode_kernel<T, D, 8>), grid, block, 0, st, a, kv, scale, out); break;
+        default: throw Error(ERR_SHAPE, "attention: heads per kv head must be 1, 2, 4 or 8");
+    }
+}
+
+void launch_attention_decode(hipStream_t st, int dtype, const QkvPostArgs& a, const KVView& kv, float scale, void* out) {
+    QTTS_CHECK(a.d == 64 || a.d == 128, ERR_SHAPE, "attention: head_dim must be 64 or 128");
+    QTTS_CHECK(a.M >= 1 && a.nh >= 1 && a.nkv >= 1 && a.nh % a.nkv == 0 && kv.d == a.d && kv.nkv == a.nkv, ERR_SHAPE, "attention: bad shape");
+    if (dtype == BF16) {
+        if (a.d == 128) launch_attn_decode_rep<bf16_t, 128>(st, a, kv, scale, (bf16_t*)out);
+        else launch_attn_decode_rep<bf16_t, 64>(st, a, kv, scale, (bf16_t*)out);
+    } else {
+        if (a.d == 128) launch_attn_decode_rep<float, 128>(st, a, kv, scale, (float*)out);
+        else launch_attn_decode_rep<float, 64>(st, a, kv, scale, (float*)out);
+    }
+}
+
 template <typename T, int D>
 static void launch_attn_rep(hipStream_t st, const float* q, const Tok* toks, const KVView& kv, int layer, int M, int nh,
                             float scale, T* out) {

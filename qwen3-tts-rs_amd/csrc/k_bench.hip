@@ -65,4 +65,51 @@ void launch_stream(hipStream_t st, const void* src, unsigned* sink, long bytes, 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Grid-wide barrier cost: `iters` barriers inside one resident grid.  Every block publishes a value before each
+// barrier and checks its neighbour's afterwards (errors are counted, not trapped).  The spin is bounded and an abort
+// flag is raised when a wait runs out, so that every wave reaches the end of the kernel whatever happens.
+__device__ __forceinline__ bool bench_barrier(unsigned* counter, unsigned* abort_flag, unsigned target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        long spins = 0;
+        while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > 4000000L || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    return __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+}
+
+__global__ void barrier_bench_kernel(unsigned* counter, unsigned* abort_flag, unsigned* slots, unsigned* errors, int iters) {
+    const unsigned nb = gridDim.x;
+    for (int it = 0; it < iters; ++it) {
+        if (threadIdx.x == 0) slots[blockIdx.x] = (unsigned)it * 7919u + blockIdx.x;
+        if (!bench_barrier(counter, abort_flag, (unsigned)(it + 1) * nb)) return;
+        if (threadIdx.x == 0) {
+            const unsigned nbr = (blockIdx.x + 1) % nb;
+            // plain load: the barrier's acquire must make the neighbour's plain store visible
+            if (slots[nbr] != (unsigned)it * 7919u + nbr) atomicAdd(errors, 1u);
+        }
+        // second barrier so that the next iteration's store cannot overtake this iteration's check
+        if (!bench_barrier(counter + 32, abort_flag, (unsigned)(it + 1) * nb)) return;
+    }
+}
+
+__global__ void null_kernel(unsigned* p) {
+    if (p == nullptr) return;
+}
+
+void launch_barrier_bench(hipStream_t st, unsigned* state /* >= 64 + blocks words, zeroed */, int blocks, int threads, int iters) {
+    QTTS_CHECK(blocks >= 1 && blocks <= 1024 && threads >= 64 && threads <= 1024 && iters >= 1 && iters <= 100000, ERR_SHAPE, "barrier bench: bad shape");
+    hipLaunchKernelGGL(barrier_bench_kernel, dim3(blocks), dim3(threads), 0, st, state, state + 16, state + 64, state + 17, iters);
+}
+void launch_null(hipStream_t st) { hipLaunchKernelGGL(null_kernel, dim3(1), dim3(64), 0, st, (unsigned*)nullptr); }
+
 }  // namespace qtts

@@ -27,6 +27,31 @@ __device__ __forceinline__ void rmsnorm_tail(const float* xrow, float ss_local, 
     }
 }
 
+__device__ __forceinline__ float4 resid_combine(const float* __restrict__ resid, const float* __restrict__ part, int KS, long ks_stride,
+                                                const float* __restrict__ bias, const float* __restrict__ scale, long off, int i) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (part) {
+        s = *reinterpret_cast<const float4*>(part + off);
+        for (int k = 1; k < KS; ++k) {
+            const float4 p = *reinterpret_cast<const float4*>(part + k * ks_stride + off);
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+    }
+    if (bias) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + i);
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    }
+    if (scale) {
+        const float4 c = *reinterpret_cast<const float4*>(scale + i);
+        s.x *= c.x; s.y *= c.y; s.z *= c.z; s.w *= c.w;
+    }
+    if (resid) {
+        const float4 r = *reinterpret_cast<const float4*>(resid + off);
+        s.x = r.x + s.x; s.y = r.y + s.y; s.z = r.z + s.z; s.w = r.w + s.w;
+    }
+    return s;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void resid_norm_kernel(const float* __restrict__ resid, const float* __restrict__ part,
                                                          int KS, long ks_stride, const float* __restrict__ bias,
@@ -34,29 +59,43 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(const float* __restrict
                                                          const float* __restrict__ norm_w, float eps, float* resid_out,
                                                          T* xn, float* xn_f32, int H) {
     __shared__ float red[32];
+    constexpr int RMAX = 4;  // rows up to 4096 wide stay in registers between the two passes
     const long row = blockIdx.x;
     float ss = 0.f;
-    for (int i = threadIdx.x * 4; i < H; i += blockDim.x * 4) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (part) {
-            s = *reinterpret_cast<const float4*>(part + row * H + i);
-            for (int k = 1; k < KS; ++k) {
-                const float4 p = *reinterpret_cast<const float4*>(part + k * ks_stride + row * H + i);
-                s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    if (H <= RMAX * 1024) {
+        float4 keep[RMAX];
+#pragma unroll
+        for (int it = 0; it < RMAX; ++it) {
+            const int i = threadIdx.x * 4 + it * 1024;
+            if (i < H) {
+                const float4 s = resid_combine(resid, part, KS, ks_stride, bias, scale, row * H + i, i);
+                *reinterpret_cast<float4*>(resid_out + row * H + i) = s;
+                keep[it] = s;
+                ss += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
             }
         }
-        if (bias) {
-            const float4 b = *reinterpret_cast<const float4*>(bias + i);
-            s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+        if (!norm_w) return;
+        const float tot = block_sum(ss, red);
+        const float m = sqrtf(tot / (float)H + eps);
+#pragma unroll
+        for (int it = 0; it < RMAX; ++it) {
+            const int i = threadIdx.x * 4 + it * 1024;
+            if (i < H) {
+                const float4 x = keep[it];
+                const float4 g = *reinterpret_cast<const float4*>(norm_w + i);
+                const float4 y = make_float4(x.x / m * g.x, x.y / m * g.y, x.z / m * g.z, x.w / m * g.w);
+                if (xn_f32) *reinterpret_cast<float4*>(xn_f32 + row * H + i) = y;
+                T* o = xn + row * H + i;
+                o[0] = from_f32<T>(y.x);
+                o[1] = from_f32<T>(y.y);
+                o[2] = from_f32<T>(y.z);
+                o[3] = from_f32<T>(y.w);
+            }
         }
-        if (scale) {
-            const float4 c = *reinterpret_cast<const float4*>(scale + i);
-            s.x *= c.x; s.y *= c.y; s.z *= c.z; s.w *= c.w;
-        }
-        if (resid) {
-            const float4 r = *reinterpret_cast<const float4*>(resid + row * H + i);
-            s.x = r.x + s.x; s.y = r.y + s.y; s.z = r.z + s.z; s.w = r.w + s.w;
-        }
+        return;
+    }
+    for (int i = threadIdx.x * 4; i < H; i += blockDim.x * 4) {
+        const float4 s = resid_combine(resid, part, KS, ks_stride, bias, scale, row * H + i, i);
         *reinterpret_cast<float4*>(resid_out + row * H + i) = s;
         ss += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
     }
@@ -180,14 +219,30 @@ template <typename TE, typename T>
 __global__ __launch_bounds__(256) void embed_sum_norm_kernel(EmbedSumArgs a, const float* __restrict__ norm_w, float eps,
                                                              float* resid_out, T* xn) {
     __shared__ float red[32];
+    __shared__ const TE* rowp[64];  // embedding row of every codebook, staged so that the gathers below are independent loads
     const int b = blockIdx.x;
     const int step = *a.step;
     const unsigned* codes = a.codes_base + (long)b * a.row_stride + (long)step * a.G;
+    if ((int)threadIdx.x < a.G) {
+        const int g = threadIdx.x;
+        const TE* table = g == 0 ? (const TE*)a.codec_emb : (const TE*)a.cp_emb[g - 1];
+        rowp[g] = table + (long)codes[g] * a.H;
+    }
+    __syncthreads();
     const float* add = step < a.trailing_len[b] ? a.trailing + ((long)b * a.Tt_max + step) * a.H : a.tts_pad;
     float ss = 0.f;
     for (int i = threadIdx.x; i < a.H; i += blockDim.x) {
-        float v = to_f32<TE>(((const TE*)a.codec_emb)[(long)codes[0] * a.H + i]);
-        for (int g = 1; g < a.G; ++g) v = v + to_f32<TE>(((const TE*)a.cp_emb[g - 1])[(long)codes[g] * a.H + i]);
+        float v = to_f32<TE>(rowp[0][i]);
+        int g = 1;
+        for (; g + 4 <= a.G; g += 4) {  // four gathers in flight; the adds stay in codebook order
+            const float e0 = to_f32<TE>(rowp[g][i]), e1 = to_f32<TE>(rowp[g + 1][i]), e2 = to_f32<TE>(rowp[g + 2][i]),
+                        e3 = to_f32<TE>(rowp[g + 3][i]);
+            v = v + e0;
+            v = v + e1;
+            v = v + e2;
+            v = v + e3;
+        }
+        for (; g < a.G; ++g) v = v + to_f32<TE>(rowp[g][i]);
         v = v + add[i];
         resid_out[(long)b * a.H + i] = v;
         ss += v * v;
@@ -197,7 +252,7 @@ __global__ __launch_bounds__(256) void embed_sum_norm_kernel(EmbedSumArgs a, con
 
 void launch_embed_sum_norm(hipStream_t st, int dtype, const EmbedSumArgs& a, const float* norm_w, float eps, float* resid_out,
                            void* xn) {
-    QTTS_CHECK(a.B >= 1 && a.H % 4 == 0, ERR_SHAPE, "embed_sum: bad shape");
+    QTTS_CHECK(a.B >= 1 && a.H % 4 == 0 && a.G >= 1 && a.G <= 64, ERR_SHAPE, "embed_sum: bad shape");
     if (a.edtype == BF16 && dtype == BF16) hipLaunchKernelGGL((embed_sum_norm_kernel<bf16_t, bf16_t>), dim3(a.B), dim3(256), 0, st, a, norm_w, eps, resid_out, (bf16_t*)xn);
     else if (a.edtype == F32 && dtype == F32) hipLaunchKernelGGL((embed_sum_norm_kernel<float, float>), dim3(a.B), dim3(256), 0, st, a, norm_w, eps, resid_out, (float*)xn);
     else throw Error(ERR_BAD_ARG, "embed_sum: embedding and activation dtypes must match");

@@ -89,14 +89,28 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
                     if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255], 1);
                 }
                 __syncthreads();
-                if (tid == 0) {
-                    int kk = sh_k, cum = 0, sel = 0;
-                    for (int bin = 255; bin >= 0; --bin) {
-                        if (cum + hist[bin] >= kk) { sel = bin; kk -= cum; break; }
-                        cum += hist[bin];
+                if (tid < 64) {
+                    // wave 0: lane l owns bins 255-4l .. 252-4l (descending); suffix counts via an inclusive wave scan
+                    const int b0 = 255 - 4 * tid;
+                    const int h0 = hist[b0], h1 = hist[b0 - 1], h2 = hist[b0 - 2], h3 = hist[b0 - 3];
+                    const int mine = h0 + h1 + h2 + h3;
+                    int incl = mine;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const int o = __shfl_up(incl, off, 64);
+                        if (tid >= off) incl += o;
                     }
-                    sh_sel = sel;
-                    sh_k = kk;
+                    const int before = incl - mine;  // candidates in strictly higher bins than this lane's
+                    const int kk = sh_k;
+                    if (before < kk && incl >= kk) {  // exactly one lane holds the k-th largest
+                        int cum = before, sel = b0;
+                        if (cum + h0 >= kk) sel = b0;
+                        else if ((cum += h0) + h1 >= kk) sel = b0 - 1;
+                        else if ((cum += h1) + h2 >= kk) sel = b0 - 2;
+                        else { cum += h2; sel = b0 - 3; }
+                        sh_sel = sel;
+                        sh_k = kk - cum;
+                    }
                 }
                 __syncthreads();
                 prefix |= ((unsigned)sh_sel) << shift;
@@ -113,12 +127,19 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
         const int i0 = tid * per, i1 = min(V, i0 + per);
         int c = 0;
         for (int i = i0; i < i1; ++i) c += lg[i] > -INFINITY ? 1 : 0;
-        cnt[tid + 1] = c;
-        if (tid == 0) cnt[0] = 0;
-        __syncthreads();
-        if (tid == 0) {
-            for (int i = 1; i <= 256; ++i) cnt[i] += cnt[i - 1];
-            sh_n = cnt[256];
+        {
+            int incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if ((tid & 63) >= off) incl += o;
+            }
+            if ((tid & 63) == 63) redi[tid >> 6] = incl;
+            __syncthreads();
+            int base = 0;
+            for (int w = 0; w < (tid >> 6); ++w) base += redi[w];
+            cnt[tid] = base + incl - c;
+            if (tid == 255) sh_n = base + incl;
         }
         __syncthreads();
         {
@@ -176,17 +197,28 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
                 __syncthreads();
             }
             // ---- softmax over the kept candidates, then the renormalised inverse-CDF draw
-            if (tid == 0) {
-                float mx = -INFINITY;
-                for (int i = 0; i < n; ++i) mx = fmaxf(mx, sv[i]);
-                float sum = 0.f;
-                for (int i = 0; i < n; ++i) sum += expf(sv[i] - mx);
-                float total = 0.f;
-                for (int i = 0; i < n; ++i) {
-                    const float p = expf(sv[i] - mx) / sum;
-                    sv[i] = p;
-                    total += p;
+            {
+                float mloc = -INFINITY;
+                for (int i = tid; i < n; i += 256) mloc = fmaxf(mloc, sv[i]);
+                mloc = wave_max(mloc);
+                if ((tid & 63) == 0) redf[tid >> 6] = mloc;
+                __syncthreads();
+                const float mx = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+                for (int i = tid; i < n; i += 256) lg[i] = expf(sv[i] - mx);   // lg is free after compaction
+                __syncthreads();
+                if (tid == 0) {
+                    float sum = 0.f;
+                    for (int i = 0; i < n; ++i) sum += lg[i];
+                    sh_f = sum;
                 }
+                __syncthreads();
+                const float sum = sh_f;
+                for (int i = tid; i < n; i += 256) sv[i] = lg[i] / sum;
+                __syncthreads();
+            }
+            if (tid == 0) {
+                float total = 0.f;
+                for (int i = 0; i < n; ++i) total += sv[i];
                 int tok = -1;
                 // Iterator::max_by keeps the LAST of equal maxima (fallbacks at sampling.rs:370-375, 391-396)
                 int best = 0;

@@ -37,6 +37,9 @@ void launch_gemm_rows(hipStream_t st, int dtype, const void* W, const void* X, f
 // ---- k_bench.hip (diagnostics)
 void launch_stream(hipStream_t st, const void* src, unsigned* sink, long bytes, int blocks, int pattern, int unroll, int ld_bytes);
 
+void launch_barrier_bench(hipStream_t st, unsigned* state, int blocks, int threads, int iters);
+void launch_null(hipStream_t st);
+
 // ---- k_elem.hip
 // x = [resid] + [scale *] (sum_ks part[ks] + [bias]); resid_out = x (f32, may alias resid); xn = rmsnorm(x) * w -> dtype;
 // xn_f32 (optional) receives the same normalised row in f32.
@@ -105,6 +108,10 @@ void launch_qkv_post(hipStream_t st, int dtype, const QkvPostArgs& a, const KVVi
 // softmax(q k^T * scale over the token's key range) v  -> out [Mpad][nh d] in dtype
 void launch_attention(hipStream_t st, int dtype, const float* q, const Tok* toks, const KVView& kv, int layer, int M, int nh,
                       float scale, void* out);
+
+// qkv_post + attention in one launch for decode steps: every token's newest key is its own position and no other token
+// of the launch attends to it
+void launch_attention_decode(hipStream_t st, int dtype, const QkvPostArgs& a, const KVView& kv, float scale, void* out);
 
 // ---- k_sample.hip
 struct SampleArgs {

@@ -91,8 +91,9 @@ struct Runner {
     // One decoder layer over M tokens (nn/decoder_layer.rs:63-86; codec: audio/tokenizer/v2/transformer.rs:279-300).
     // On entry x holds the residual stream and xn = RMSNorm_ln1(x); on exit xn = RMSNorm_next(x) with `next_norm`
     // the following layer's input norm (or the stack's final norm).
+    // `decode`: every token's key range ends at its own position and tokens of the launch do not attend to each other
     void layer(const StackW& s, int l, int M, const Tok* toks, const KVView& kv, int kv_layer, const float* next_norm, void* xn_out,
-               float* xn_f32_out) {
+               float* xn_f32_out, bool decode = false) {
         const StackCfg& c = s.cfg;
         const LayerW& w = s.layers[(size_t)l];
         const int nq = c.nh * c.d, nqkv = (c.nh + 2 * c.nkv) * c.d;
@@ -103,8 +104,12 @@ struct Runner {
         qa.q_norm = w.q_norm; qa.k_norm = w.k_norm; qa.eps = c.eps; qa.cos = s.cos.as<float>(); qa.sin = s.sin.as<float>();
         qa.rope_mode = 0; qa.toks = toks; qa.M = M; qa.nh = c.nh; qa.nkv = c.nkv; qa.d = c.d; qa.layer = kv_layer;
         qa.q_out = g.q.as<float>();
-        launch_qkv_post(st, dt, qa, kv);
-        launch_attention(st, dt, g.q.as<float>(), toks, kv, kv_layer, M, c.nh, (float)std::pow((double)c.d, -0.5), g.attn.p);
+        if (decode) {
+            launch_attention_decode(st, dt, qa, kv, (float)std::pow((double)c.d, -0.5), g.attn.p);
+        } else {
+            launch_qkv_post(st, dt, qa, kv);
+            launch_attention(st, dt, g.q.as<float>(), toks, kv, kv_layer, M, c.nh, (float)std::pow((double)c.d, -0.5), g.attn.p);
+        }
         ks = ks_for(M, c.hidden, nq);
         gemm(w.o, g.attn.p, M, c.hidden, nq, ks, nq);
         launch_resid_norm(st, dt, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), w.o_bias, w.ls_attn, w.ln2, c.eps,
@@ -119,11 +124,12 @@ struct Runner {
     }
 
     // kv_per_layer: the KV view holds every layer (decode caches); otherwise one layer's worth is reused
-    void stack(const StackW& s, int M, const Tok* toks, const KVView& kv, void* final_xn, float* final_xn_f32, bool kv_per_layer = true) {
+    void stack(const StackW& s, int M, const Tok* toks, const KVView& kv, void* final_xn, float* final_xn_f32, bool kv_per_layer = true,
+               bool decode = false) {
         for (int l = 0; l < s.cfg.layers; ++l) {
             const bool last = l + 1 == s.cfg.layers;
             layer(s, l, M, toks, kv, kv_per_layer ? l : 0, last ? s.final_norm : s.layers[(size_t)l + 1].ln1, last ? final_xn : g.xn.p,
-                  last ? final_xn_f32 : nullptr);
+                  last ? final_xn_f32 : nullptr, decode);
         }
     }
 };
