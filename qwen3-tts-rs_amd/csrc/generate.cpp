@@ -97,6 +97,10 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     const int dt = m.dtype;
     const size_t es = R.es;
     const bool use_graph = dbg ? dbg->use_graph != 0 : true;
+    // Experimental decode schedule with epilogue-fused GEMMs (k_gemm_fused.hip): 5 launches per layer instead of 8, token-exact,
+    // but its one-block-per-tile GEMM is slower at 64 rows than the split-K kernels, so it is opt-in (QTTS_FUSED=1).
+    static const bool fused_env = getenv("QTTS_FUSED") && atoi(getenv("QTTS_FUSED")) != 0;
+    const bool fused = fused_env && 2 * n <= 256;
     g.timer.enabled = dbg && dbg->profile_gemm && !use_graph;
     g.timer.used = 0;
     g.timer.bytes = 0;
@@ -233,6 +237,14 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     g.ws.q.ensure(rows * QD * 4);
     g.ws.attn.ensure(rows * QD * es);
     g.ws.act.ensure(rows * Imax * es);
+    if (fused) {
+        g.ws.out.ensure(rows * (size_t)Nmax * 4);
+        g.ws.xb.ensure(rows * Wmax * es);
+        g.ws.ss_ld = (long)rows;
+        const size_t max_tiles = (size_t)Wmax / 16 + 1;
+        g.ws.ssA.ensure(max_tiles * rows * 4);
+        g.ws.ssB.ensure(max_tiles * rows * 4);
+    }
     const size_t cp_rows = (size_t)gemm_pad_rows(2 * B) + 64;
     g.cp_in_t.ensure(cp_rows * H * es);
     g.cp_in_f.ensure(cp_rows * H * 4);
@@ -422,7 +434,68 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     };
 
     // logits -> cb0 -> code predictor -> next talker input (generation.rs:1029-1106)
+    // fused path: every GEMM carries its consumer's element-wise work (k_gemm_fused.hip)
+    auto frame_tail_fused = [&]() {
+        float* ssA = g.ws.ssA.as<float>();
+        GemmEpi eh{};
+        eh.mode = GEMM_EPI_PLAIN; eh.out_f32 = g.ws.out.as<float>(); eh.ld_out = V;
+        R.gemm_fused(m.codec_head, hid_t, H, B, V, H, eh);
+        sample(g.ws.out.as<float>(), V, 0, true);
+        const Tok* ct = g.toks_cp.as<Tok>();
+        for (int j = 0; j < G - 1; ++j) {
+            const int M = j == 0 ? 2 * B : B;
+            int nt;
+            if (m.proj) {
+                const void* X;
+                if (j == 0) {
+                    launch_gather_codes(st, m.codec_emb, dt, g.codes.as<unsigned>(), row_stride, d_step, G, 0, (char*)g.cp_in_t.p + (size_t)B * H * es, dt, B, H);
+                    X = g.cp_in_t.p;
+                } else {
+                    launch_gather_codes(st, m.cp_emb[(size_t)j - 1], dt, g.codes.as<unsigned>(), row_stride, d_step, G, j, g.ws.act.p, dt, B, H);
+                    X = g.ws.act.p;
+                }
+                GemmEpi ep{};
+                ep.mode = GEMM_EPI_RESID; ep.bias = m.proj_b; ep.x_out = g.ws.x.as<float>(); ep.xb_out = g.ws.xb.p; ep.nw = m.cp.layers[0].ln1;
+                ep.ss_out = ssA;
+                R.gemm_fused(m.proj, X, H, M, Hc, H, ep);
+                nt = gemm_fused_ntiles(M, Hc, GEMM_EPI_RESID);
+            } else {
+                const float* src;
+                if (j == 0) {
+                    launch_gather_codes(st, m.codec_emb, dt, g.codes.as<unsigned>(), row_stride, d_step, G, 0, g.cp_in_f.as<float>() + (size_t)B * H, F32, B, H);
+                    src = g.cp_in_f.as<float>();
+                } else {
+                    launch_gather_codes(st, m.cp_emb[(size_t)j - 1], dt, g.codes.as<unsigned>(), row_stride, d_step, G, j, g.ws.q.p, F32, B, H);
+                    src = g.ws.q.as<float>();
+                }
+                launch_rows_prep(st, dt, src, m.cp.layers[0].ln1, g.ws.x.as<float>(), g.ws.xb.p, ssA, M, Hc);
+                nt = 1;
+            }
+            nt = R.stack_fused(m.cp, M, j == 0 ? ct : ct + 2 * B + (size_t)j * B, g.cp.kv, nt, true, j != 0);
+            // lm_head j on the newest position of every row (code_predictor.rs:464,514)
+            const size_t roff = j == 0 ? (size_t)B : 0;
+            GemmEpi el{};
+            el.mode = GEMM_EPI_PLAIN; el.ss_in = ssA + roff; el.ntiles_in = nt; el.H_in = Hc; el.eps = c.cp.eps; el.out_f32 = g.ws.out.as<float>();
+            el.ld_out = Vc;
+            R.gemm_fused(m.cp_head[(size_t)j], (char*)g.ws.xb.p + roff * Hc * es, Hc, B, Vc, Hc, el);
+            sample(g.ws.out.as<float>(), Vc, j + 1, false);
+        }
+        EmbedSumArgs ea{};
+        ea.codec_emb = m.codec_emb; ea.cp_emb = (const void* const*)m.cp_emb_ptrs.p; ea.edtype = dt;
+        ea.codes_base = g.codes.as<unsigned>(); ea.row_stride = row_stride; ea.step = d_step;
+        ea.trailing = g.trailing.as<float>(); ea.trailing_len = g.trailing_len.as<int>(); ea.Tt_max = Tt_max;
+        ea.tts_pad = tts_pad_row; ea.G = G; ea.H = H; ea.B = B;
+        launch_embed_sum_norm(st, dt, ea, m.talker.layers[0].ln1, c.talker.eps, g.ws.x.as<float>(), g.ws.xb.p, ssA);
+        launch_advance_step(st, d_step);
+    };
+    auto talker_step_fused = [&]() {
+        launch_make_decode_toks(st, g.row_len.as<int>(), g.toks_dec.as<Tok>(), B, c.talker.window);
+        const int nt = R.stack_fused(m.talker, B, g.toks_dec.as<Tok>(), g.talker.kv, 1, true, true);
+        // post-final-norm hidden state (talker.rs:147-148): input of the codec head and of the code predictor
+        launch_norm_rows(st, dt, g.ws.x.as<float>(), g.ws.ssA.as<float>(), nt, g.ws.ss_ld, m.talker.final_norm, c.talker.eps, hid_t, hid_f, B, H);
+    };
     auto frame_tail = [&](bool eager_trace) {
+        if (fused) { frame_tail_fused(); return; }
         R.gemm(m.codec_head, hid_t, B, V, H, 1, H);
         if (eager_trace && trace_l) {
             // step index is only known on the device; trace copies use the host's mirror of it
@@ -470,6 +543,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         launch_advance_step(st, d_step);
     };
     auto talker_step = [&]() {  // generation.rs:1002-1026
+        if (fused) { talker_step_fused(); return; }
         launch_make_decode_toks(st, g.row_len.as<int>(), g.toks_dec.as<Tok>(), B, c.talker.window);
         R.stack(m.talker, B, g.toks_dec.as<Tok>(), g.talker.kv, hid_t, hid_f, true, true);
     };

@@ -217,7 +217,7 @@ void launch_assemble(hipStream_t st, const float* text_rows, const int* text_idx
 // (nn/generation.rs:1096-1106) + the next layer-0 input norm.  Adds run in codebook order in f32.
 template <typename TE, typename T>
 __global__ __launch_bounds__(256) void embed_sum_norm_kernel(EmbedSumArgs a, const float* __restrict__ norm_w, float eps,
-                                                             float* resid_out, T* xn) {
+                                                             float* resid_out, T* xn, float* ss_out) {
     __shared__ float red[32];
     __shared__ const TE* rowp[64];  // embedding row of every codebook, staged so that the gathers below are independent loads
     const int b = blockIdx.x;
@@ -245,17 +245,67 @@ __global__ __launch_bounds__(256) void embed_sum_norm_kernel(EmbedSumArgs a, con
         for (; g < a.G; ++g) v = v + to_f32<TE>(rowp[g][i]);
         v = v + add[i];
         resid_out[(long)b * a.H + i] = v;
+        if (ss_out) xn[(long)b * a.H + i] = from_f32<T>(v * norm_w[i]);  // split norm: 1/rms is applied by the consuming GEMM
         ss += v * v;
+    }
+    if (ss_out) {
+        const float tot = block_sum(ss, red);
+        if (threadIdx.x == 0) ss_out[b] = tot;
+        return;
     }
     rmsnorm_tail<T>(resid_out + (long)b * a.H, ss, norm_w, eps, xn + (long)b * a.H, nullptr, a.H, red);
 }
 
 void launch_embed_sum_norm(hipStream_t st, int dtype, const EmbedSumArgs& a, const float* norm_w, float eps, float* resid_out,
-                           void* xn) {
+                           void* xn, float* ss_out) {
     QTTS_CHECK(a.B >= 1 && a.H % 4 == 0 && a.G >= 1 && a.G <= 64, ERR_SHAPE, "embed_sum: bad shape");
-    if (a.edtype == BF16 && dtype == BF16) hipLaunchKernelGGL((embed_sum_norm_kernel<bf16_t, bf16_t>), dim3(a.B), dim3(256), 0, st, a, norm_w, eps, resid_out, (bf16_t*)xn);
-    else if (a.edtype == F32 && dtype == F32) hipLaunchKernelGGL((embed_sum_norm_kernel<float, float>), dim3(a.B), dim3(256), 0, st, a, norm_w, eps, resid_out, (float*)xn);
+    if (a.edtype == BF16 && dtype == BF16) hipLaunchKernelGGL((embed_sum_norm_kernel<bf16_t, bf16_t>), dim3(a.B), dim3(256), 0, st, a, norm_w, eps, resid_out, (bf16_t*)xn, ss_out);
+    else if (a.edtype == F32 && dtype == F32) hipLaunchKernelGGL((embed_sum_norm_kernel<float, float>), dim3(a.B), dim3(256), 0, st, a, norm_w, eps, resid_out, (float*)xn, ss_out);
     else throw Error(ERR_BAD_ARG, "embed_sum: embedding and activation dtypes must match");
+}
+
+// Split RMSNorm helpers for the fused decode GEMMs (nn/norm.rs:17-23): a row producer emits xb = T(x * w) and the
+// row's sum of squares; the consuming GEMM divides by sqrt(ss / H + eps).
+//   rows_prep: x (f32 rows) -> [x_out copy], xb, ss[row]            norm_rows: x, ss partials -> T(x / m * w) [+ f32 copy]
+template <typename T>
+__global__ __launch_bounds__(256) void rows_prep_kernel(const float* __restrict__ x, const float* __restrict__ nw, float* x_out, T* xb,
+                                                        float* ss_out, int H) {
+    __shared__ float red[32];
+    const long row = blockIdx.x;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        const float v = x[row * H + i];
+        if (x_out) x_out[row * H + i] = v;
+        xb[row * H + i] = from_f32<T>(v * nw[i]);
+        ss += v * v;
+    }
+    const float tot = block_sum(ss, red);
+    if (threadIdx.x == 0) ss_out[row] = tot;
+}
+void launch_rows_prep(hipStream_t st, int dtype, const float* x, const float* nw, float* x_out, void* xb, float* ss_out, int M, int H) {
+    QTTS_CHECK(M >= 1 && H >= 1 && x && nw && xb && ss_out, ERR_BAD_ARG, "rows_prep: bad argument");
+    if (dtype == BF16) hipLaunchKernelGGL(rows_prep_kernel<bf16_t>, dim3(M), dim3(256), 0, st, x, nw, x_out, (bf16_t*)xb, ss_out, H);
+    else hipLaunchKernelGGL(rows_prep_kernel<float>, dim3(M), dim3(256), 0, st, x, nw, x_out, (float*)xb, ss_out, H);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict__ x, const float* __restrict__ ss, int ntiles, long ss_ld,
+                                                        const float* __restrict__ nw, float eps, T* out, float* out_f32, int H) {
+    const long row = blockIdx.x;
+    float tot = 0.f;
+    for (int t = 0; t < ntiles; ++t) tot += ss[t * ss_ld + row];
+    const float m = sqrtf(tot / (float)H + eps);
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        const float y = x[row * H + i] / m * nw[i];
+        out[row * H + i] = from_f32<T>(y);
+        if (out_f32) out_f32[row * H + i] = y;
+    }
+}
+void launch_norm_rows(hipStream_t st, int dtype, const float* x, const float* ss, int ntiles, long ss_ld, const float* nw, float eps,
+                      void* out, float* out_f32, int M, int H) {
+    QTTS_CHECK(M >= 1 && H >= 1 && ntiles >= 1 && x && ss && nw && out, ERR_BAD_ARG, "norm_rows: bad argument");
+    if (dtype == BF16) hipLaunchKernelGGL(norm_rows_kernel<bf16_t>, dim3(M), dim3(256), 0, st, x, ss, ntiles, ss_ld, nw, eps, (bf16_t*)out, out_f32, H);
+    else hipLaunchKernelGGL(norm_rows_kernel<float>, dim3(M), dim3(256), 0, st, x, ss, ntiles, ss_ld, nw, eps, (float*)out, out_f32, H);
 }
 
 // sum_ref_code_embeddings (qwen_tts/src/nn/generation.rs:242-273): dst[rows[i]] = codec_emb[c0] + sum_g cp_emb[g-1][c_g]

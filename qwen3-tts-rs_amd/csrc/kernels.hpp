@@ -34,6 +34,29 @@ void launch_gemm(hipStream_t st, int dtype, const void* W, const void* X, float*
 void launch_gemm_rows(hipStream_t st, int dtype, const void* W, const void* X, float* out, long M, int N, int K, int ldx, int taps,
                       long tap_stride);
 
+// ---- k_gemm_fused.hip: decode-path GEMM (one block per output tile, full K) with the consumer's epilogue fused in
+enum { GEMM_EPI_PLAIN = 0, GEMM_EPI_RESID = 1, GEMM_EPI_SWIGLU = 2 };
+struct GemmEpi {
+    int mode;
+    const float* ss_in;    // optional [ntiles_in][ss_ld]: per-row partial sums of squares of the input's f32 source
+    long ss_ld;            // row stride of ss_in / ss_out
+    int ntiles_in, H_in;   // row scale = 1 / sqrt(sum_t ss_in[t][m] / H_in + eps)
+    float eps;
+    const float* bias;     // [N] or null
+    float* out_f32;        // PLAIN: [rows][ld_out]
+    int ld_out;
+    const float* resid;    // RESID: optional [rows][N] f32 (may alias x_out)
+    float* x_out;          // RESID: [rows][N] f32
+    void* xb_out;          // RESID: [rows][N] model dtype = x * nw
+    const float* nw;       // RESID: optional [N] norm weight of the consumer
+    float* ss_out;         // RESID: optional [gemm_fused_ntiles][ss_ld]
+    void* act;             // SWIGLU: [rows][N/2] model dtype
+};
+int gemm_fused_rows(int M);
+int gemm_fused_ntiles(int M, int N, int mode);  // tiles a RESID launch writes to ss_out
+// X: [rows][ldx] model dtype.  W rows for SWIGLU are interleaved: every 32 rows = 16 gate rows then the matching 16 up rows.
+void launch_gemm_fused(hipStream_t st, int dtype, const void* W, const void* X, int ldx, int M, int N, int K, const GemmEpi& e);
+
 // ---- k_bench.hip (diagnostics)
 void launch_stream(hipStream_t st, const void* src, unsigned* sink, long bytes, int blocks, int pattern, int unroll, int ld_bytes);
 
@@ -73,8 +96,12 @@ struct EmbedSumArgs {
     const float* tts_pad;           // [H] f32
     int G, H, B;
 };
+// ss_out != null selects the split norm: xn = T(x * norm_w) and ss_out[b] = sum x^2 (the consuming GEMM applies 1/rms)
 void launch_embed_sum_norm(hipStream_t st, int dtype, const EmbedSumArgs& a, const float* norm_w, float eps, float* resid_out,
-                           void* xn);
+                           void* xn, float* ss_out = nullptr);
+void launch_rows_prep(hipStream_t st, int dtype, const float* x, const float* nw, float* x_out, void* xb, float* ss_out, int M, int H);
+void launch_norm_rows(hipStream_t st, int dtype, const float* x, const float* ss, int ntiles, long ss_ld, const float* nw, float eps,
+                      void* out, float* out_f32, int M, int H);
 // code-predictor input rows: dst[b] = table[codes[b][g]] cast to dtype (codes laid out as in EmbedSumArgs)
 void launch_gather_codes(hipStream_t st, const void* table, int tdtype, const unsigned* codes_base, long row_stride,
                          const int* step, int G, int g, void* dst, int ddtype, int B, int H);

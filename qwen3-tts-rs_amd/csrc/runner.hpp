@@ -10,6 +10,9 @@ namespace qtts {
 
 struct Workspace {
     DevBuf x, xn, part, q, attn, act;  // residual f32 | gemm input T | GEMM output f32 | q f32 | attn T | mlp act T
+    // fused decode path: reduced GEMM output f32 | x * norm_w (T) | per-row sum-of-squares partials (two generations)
+    DevBuf out, xb, ssA, ssB;
+    long ss_ld = 0;  // row stride of ssA / ssB
 };
 
 struct GemmTimer {
@@ -121,6 +124,77 @@ struct Runner {
         gemm(w.down, g.act.p, M, c.hidden, c.inter, ks, c.inter);
         launch_resid_norm(st, dt, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), nullptr, w.ls_mlp, next_norm, c.eps,
                           g.x.as<float>(), xn_out, xn_f32_out, M, c.hidden);
+    }
+
+    // ---- fused decode path (k_gemm_fused.hip): the residual stream is (x f32, xb = T(x * next norm weight), ssA partials)
+    void gemm_fused(const void* W, const void* X, int ldx, int M, int N, int K, GemmEpi e) {
+        e.ss_ld = g.ss_ld;
+        const bool time = timer && timer->enabled && timer->used + 2 <= 400000;
+        if (time) {
+            while (timer->ev.size() < timer->used + 2) {
+                hipEvent_t ev;
+                QTTS_HIP(hipEventCreate(&ev));
+                timer->ev.push_back(ev);
+            }
+            QTTS_HIP(hipEventRecord(timer->ev[timer->used], st));
+        }
+        launch_gemm_fused(st, dt, W, X, ldx, M, N, K, e);
+        if (time) {
+            QTTS_HIP(hipEventRecord(timer->ev[timer->used + 1], st));
+            timer->used += 2;
+            timer->bytes += (double)N * K * es;
+            timer->shape.push_back(M);
+            timer->shape.push_back(N);
+            timer->shape.push_back(K);
+        }
+    }
+
+    // One decoder layer on the fused path.  In: x, xb = T(x * ln1), ssA (nt_in tiles).  Out: x, xb = T(x * next_norm), ssA;
+    // returns the tile count of the new ssA.
+    int layer_fused(const StackW& s, int l, int M, const Tok* toks, const KVView& kv, int kv_layer, const float* next_norm, int nt_in,
+                    bool decode) {
+        const StackCfg& c = s.cfg;
+        const LayerW& w = s.layers[(size_t)l];
+        const int nq = c.nh * c.d, nqkv = (c.nh + 2 * c.nkv) * c.d;
+        GemmEpi e{};
+        e.mode = GEMM_EPI_PLAIN; e.ss_in = g.ssA.as<float>(); e.ntiles_in = nt_in; e.H_in = c.hidden; e.eps = c.eps; e.bias = w.qkv_bias;
+        e.out_f32 = g.out.as<float>(); e.ld_out = nqkv;
+        gemm_fused(w.qkv, g.xb.p, c.hidden, M, nqkv, c.hidden, e);
+        QkvPostArgs qa{};
+        qa.part = g.out.as<float>(); qa.KS = 1; qa.ks_stride = 0; qa.bias = nullptr;
+        qa.q_norm = w.q_norm; qa.k_norm = w.k_norm; qa.eps = c.eps; qa.cos = s.cos.as<float>(); qa.sin = s.sin.as<float>();
+        qa.rope_mode = 0; qa.toks = toks; qa.M = M; qa.nh = c.nh; qa.nkv = c.nkv; qa.d = c.d; qa.layer = kv_layer;
+        qa.q_out = g.q.as<float>();
+        const float scale = (float)std::pow((double)c.d, -0.5);
+        if (decode) {
+            launch_attention_decode(st, dt, qa, kv, scale, g.attn.p);
+        } else {
+            launch_qkv_post(st, dt, qa, kv);
+            launch_attention(st, dt, g.q.as<float>(), toks, kv, kv_layer, M, c.nh, scale, g.attn.p);
+        }
+        GemmEpi eo{};
+        eo.mode = GEMM_EPI_RESID; eo.bias = w.o_bias; eo.resid = g.x.as<float>(); eo.x_out = g.x.as<float>(); eo.xb_out = g.xb.p;
+        eo.nw = w.ln2; eo.ss_out = g.ssB.as<float>();
+        gemm_fused(w.o, g.attn.p, nq, M, c.hidden, nq, eo);
+        const int nt_b = gemm_fused_ntiles(M, c.hidden, GEMM_EPI_RESID);
+        GemmEpi eg{};
+        eg.mode = GEMM_EPI_SWIGLU; eg.ss_in = g.ssB.as<float>(); eg.ntiles_in = nt_b; eg.H_in = c.hidden; eg.eps = c.eps; eg.act = g.act.p;
+        gemm_fused(w.gate_up_il, g.xb.p, c.hidden, M, 2 * c.inter, c.hidden, eg);
+        GemmEpi ed{};
+        ed.mode = GEMM_EPI_RESID; ed.resid = g.x.as<float>(); ed.x_out = g.x.as<float>(); ed.xb_out = g.xb.p; ed.nw = next_norm;
+        ed.ss_out = g.ssA.as<float>();
+        gemm_fused(w.down, g.act.p, c.inter, M, c.hidden, c.inter, ed);
+        return gemm_fused_ntiles(M, c.hidden, GEMM_EPI_RESID);
+    }
+
+    // whole stack on the fused path; afterwards xb = T(x * final_norm) and ssA holds the returned number of tiles
+    int stack_fused(const StackW& s, int M, const Tok* toks, const KVView& kv, int nt_in, bool kv_per_layer, bool decode) {
+        int nt = nt_in;
+        for (int l = 0; l < s.cfg.layers; ++l) {
+            const bool last = l + 1 == s.cfg.layers;
+            nt = layer_fused(s, l, M, toks, kv, kv_per_layer ? l : 0, last ? s.final_norm : s.layers[(size_t)l + 1].ln1, nt, decode);
+        }
+        return nt;
     }
 
     // kv_per_layer: the KV view holds every layer (decode caches); otherwise one layer's worth is reused
