@@ -216,17 +216,12 @@ Geometry make_geometry(const CodecCfg& c, const CodecState& s, int U, int Tm) {
     need(M0, std::max({s.DcP, s.latP}));
     need_acc(M0, s.latP);
     for (int i = 0; i < g.nup; ++i) {
-        const long Min = U * g.S[(size_t)i], Mout = U * g.S[(size_t)i + 1];
+        const long Mout = U * g.S[(size_t)i + 1];
         need(Mout, s.ups[(size_t)i].pw1.CoutP);
-        need_acc(Min, s.ups[(size_t)i].ct.N);
-        need_acc(Mout, s.ups[(size_t)i].pw1.N);
     }
-    need_acc(U * g.S[(size_t)g.nup], s.dec0.N);
     need(U * g.S[(size_t)g.nup], s.dec0.CoutP);
     for (int b = 0; b < g.nb; ++b) {
-        const long Min = U * g.S[(size_t)g.nup + b], Mout = U * g.S[(size_t)g.nup + b + 1];
-        need_acc(Min, s.blocks[(size_t)b].ct.N);
-        need_acc(Mout, s.blocks[(size_t)b].ct.CoutP);
+        const long Mout = U * g.S[(size_t)g.nup + b + 1];
         need(Mout, s.blocks[(size_t)b].ct.CoutP);
         g.res_elems = std::max(g.res_elems, (size_t)(Mout + SLACK_ROWS) * (size_t)s.blocks[(size_t)b].ct.CoutP);
     }
@@ -243,8 +238,20 @@ struct Decoder {
 
     explicit Decoder(Model& model) : m(model), s(*model.codec_state), st(model.ctx->stream), dt(model.dtype), es(dtype_size(model.dtype)) {}
 
-    void gemm(const GemmW& g, const void* X, long M, int ldx) {
-        launch_gemm_rows(st, dt, g.w.p, X, s.acc.as<float>(), M, g.N, g.K, ldx, g.taps, (long)g.dil * ldx);
+    // A conv is issued in two steps so that the call sites read like the reference's forward(): gemm() names the
+    // weights and the input view, epilogue() launches the GEMM with that element-wise tail applied in registers.
+    struct Pending {
+        const GemmW* g = nullptr;
+        const void* X = nullptr;
+        long M = 0;
+        int ldx = 0;
+    } pend;
+    void gemm(const GemmW& g, const void* X, long M, int ldx) { pend = Pending{&g, X, M, ldx}; }
+    void epilogue(ConvEpi e) {
+        QTTS_CHECK(pend.g != nullptr && e.M == pend.M && e.N == pend.g->N, ERR_STATE, "codec decode: epilogue does not match the pending GEMM");
+        e.acc = nullptr;
+        launch_gemm_rows_epi(st, dt, pend.g->w.p, pend.X, pend.g->K, pend.ldx, pend.g->taps, (long)pend.g->dil * pend.ldx, e);
+        pend = Pending{};
     }
     void run_group(const uint32_t* d_codes, int T_max, const std::vector<Piece>& ps, float* wav_out, int64_t wav_stride);
 };
@@ -318,9 +325,9 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
     QTTS_HIP(hipMemsetAsync(s.Bf.p, 0, (size_t)(M0 + SLACK_ROWS) * s.latP * es, st));
     {
         ConvEpi e{};
-        e.acc = s.acc.as<float>(); e.M = M0; e.N = s.pre_conv.N; e.r = 1; e.Cout = s.pre_conv.CoutP; e.bias = s.pre_conv.bias.as<float>();
+        e.M = M0; e.N = s.pre_conv.N; e.r = 1; e.Cout = s.pre_conv.CoutP; e.bias = s.pre_conv.bias.as<float>();
         e.lens = d_len(0); e.S_in = S[0]; e.S_out = S[0]; e.P_out = 0; e.ld_out = s.latP; e.out = s.Bf.p;
-        launch_conv_epilogue(st, dt, e);
+        epilogue(e);
     }
     // transformer over every strip row (rows past a strip's length are computed and ignored)
     {
@@ -403,9 +410,9 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         QTTS_HIP(hipMemsetAsync(s.R.p, 0, (size_t)(Mout + SLACK_ROWS) * s.latP * es, st));
         {
             ConvEpi e{};
-            e.acc = s.acc.as<float>(); e.M = Min; e.N = up.ct.N; e.r = up.ct.r; e.Cout = up.ct.CoutP; e.bias = up.ct.bias.as<float>();
+            e.M = Min; e.N = up.ct.N; e.r = up.ct.r; e.Cout = up.ct.CoutP; e.bias = up.ct.bias.as<float>();
             e.lens = d_len(i); e.S_in = S[(size_t)i]; e.S_out = S[(size_t)i + 1]; e.P_out = Pn; e.ld_out = s.latP; e.out = s.R.p;
-            launch_conv_epilogue(st, dt, e);
+            epilogue(e);
         }
         // ConvNeXt: depthwise conv + LayerNorm -> A ; pwconv1 + GELU -> Bf ; pwconv2 * gamma + residual -> R (in place)
         launch_dwconv_ln(st, dt, s.R.p, up.dw_w.as<float>(), up.dw_b.as<float>(), up.ln_w.as<float>(), up.ln_b.as<float>(), d_len(i + 1), U,
@@ -413,18 +420,18 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         gemm(up.pw1, (const char*)s.A.p + (size_t)Pn * s.latP * es, Mout, s.latP);
         {
             ConvEpi e{};
-            e.acc = s.acc.as<float>(); e.M = Mout; e.N = up.pw1.N; e.r = 1; e.Cout = up.pw1.CoutP; e.bias = up.pw1.bias.as<float>();
+            e.M = Mout; e.N = up.pw1.N; e.r = 1; e.Cout = up.pw1.CoutP; e.bias = up.pw1.bias.as<float>();
             e.act = 1; e.lens = d_len(i + 1); e.S_in = S[(size_t)i + 1]; e.S_out = S[(size_t)i + 1]; e.P_out = 0; e.ld_out = up.pw1.CoutP;
             e.out = s.Bf.p;
-            launch_conv_epilogue(st, dt, e);
+            epilogue(e);
         }
         gemm(up.pw2, s.Bf.p, Mout, up.pw1.CoutP);
         {
             ConvEpi e{};
-            e.acc = s.acc.as<float>(); e.M = Mout; e.N = up.pw2.N; e.r = 1; e.Cout = up.pw2.CoutP; e.bias = up.pw2.bias.as<float>();
+            e.M = Mout; e.N = up.pw2.N; e.r = 1; e.Cout = up.pw2.CoutP; e.bias = up.pw2.bias.as<float>();
             e.scale = up.gamma.as<float>(); e.resid = s.R.p; e.lens = d_len(i + 1); e.S_in = S[(size_t)i + 1]; e.S_out = S[(size_t)i + 1];
             e.P_out = Pn; e.ld_out = s.latP; e.out = s.R.p;
-            launch_conv_epilogue(st, dt, e);
+            epilogue(e);
         }
         std::swap(s.A, s.R);  // the stage's result becomes the current tensor
         Pcur = Pn;
@@ -437,10 +444,10 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         const long M = U * S[(size_t)nup];
         gemm(s.dec0, (const char*)s.A.p + (size_t)(Pcur - 6) * s.latP * es, M, s.latP);
         ConvEpi e{};
-        e.acc = s.acc.as<float>(); e.M = M; e.N = s.dec0.N; e.r = 1; e.Cout = CP; e.bias = s.dec0.bias.as<float>();
+        e.M = M; e.N = s.dec0.N; e.r = 1; e.Cout = CP; e.bias = s.dec0.bias.as<float>();
         e.lens = d_len(nup); e.S_in = S[(size_t)nup]; e.S_out = S[(size_t)nup]; e.P_out = 0; e.ld_out = CP;
         e.out2 = s.Bf.p; e.alpha_exp = s.blocks[0].s0.a.as<float>(); e.beta_den = s.blocks[0].s0.den.as<float>();
-        launch_conv_epilogue(st, dt, e);
+        epilogue(e);
     }
     // Inside a block R is the residual stream and A the activated input of the next conv, both with maxpad leading
     // zero rows per strip.  `xin` is the activated input of the block's transposed conv: Bf for the first block,
@@ -456,10 +463,10 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         QTTS_HIP(hipMemsetAsync(s.A.p, 0, (size_t)(Mout + SLACK_ROWS) * CPo * es, st));
         {
             ConvEpi e{};
-            e.acc = s.acc.as<float>(); e.M = Min; e.N = blk.ct.N; e.r = blk.ct.r; e.Cout = CPo; e.bias = blk.ct.bias.as<float>();
+            e.M = Min; e.N = blk.ct.N; e.r = blk.ct.r; e.Cout = CPo; e.bias = blk.ct.bias.as<float>();
             e.lens = d_lenm1(si); e.S_in = S[(size_t)si]; e.S_out = S[(size_t)so]; e.P_out = Pn; e.ld_out = CPo;
             e.out_f32 = s.Rf.as<float>(); e.out2 = s.A.p; e.alpha_exp = blk.u[0].a1.a.as<float>(); e.beta_den = blk.u[0].a1.den.as<float>();
-            launch_conv_epilogue(st, dt, e);
+            epilogue(e);
         }
         for (int u = 0; u < 3; ++u) {
             const CodecState::Unit& un = blk.u[u];
@@ -467,22 +474,22 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
             gemm(un.c1, (const char*)s.A.p + (size_t)(Pn - 6 * un.c1.dil) * CPo * es, Mout, CPo);
             {
                 ConvEpi e{};
-                e.acc = s.acc.as<float>(); e.M = Mout; e.N = CPo; e.r = 1; e.Cout = CPo; e.bias = un.c1.bias.as<float>();
+                e.M = Mout; e.N = CPo; e.r = 1; e.Cout = CPo; e.bias = un.c1.bias.as<float>();
                 e.lens = d_len(so); e.S_in = S[(size_t)so]; e.S_out = S[(size_t)so]; e.P_out = 0; e.ld_out = CPo;
                 e.out2 = s.Bf.p; e.alpha_exp = un.a2.a.as<float>(); e.beta_den = un.a2.den.as<float>();
-                launch_conv_epilogue(st, dt, e);
+                epilogue(e);
             }
             // conv2 (k = 1) + residual: R += conv2(Bf); A = snake_next(R).  After the last unit the raw sum is dead.
             gemm(un.c2, s.Bf.p, Mout, CPo);
             {
                 ConvEpi e{};
-                e.acc = s.acc.as<float>(); e.M = Mout; e.N = CPo; e.r = 1; e.Cout = CPo; e.bias = un.c2.bias.as<float>();
+                e.M = Mout; e.N = CPo; e.r = 1; e.Cout = CPo; e.bias = un.c2.bias.as<float>();
                 e.resid_f32 = s.Rf.as<float>(); e.lens = d_len(so); e.S_in = S[(size_t)so]; e.S_out = S[(size_t)so]; e.P_out = Pn; e.ld_out = CPo;
                 const Snake& nx = u < 2 ? blk.u[u + 1].a1 : (b + 1 < nb ? s.blocks[(size_t)b + 1].s0 : s.sfinal);
                 e.alpha_exp = nx.a.as<float>(); e.beta_den = nx.den.as<float>();
                 e.out_f32 = s.Rf.as<float>();
                 e.out2 = s.A.p;
-                launch_conv_epilogue(st, dt, e);
+                epilogue(e);
             }
         }
         CP = CPo;

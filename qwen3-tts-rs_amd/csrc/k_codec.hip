@@ -5,8 +5,7 @@
 // tensor, audio/tokenizer/v2/causal_conv.rs:91-101) followed by T time steps.  With that layout a
 // causal conv is a GEMM whose taps are row offsets, and a transposed conv with stride r is a GEMM with
 // N = r * Cout whose output rows are already the r-times longer sequence.
-#include "device_utils.hpp"
-#include "kernels.hpp"
+#include "conv_epi.hpp"
 
 namespace qtts {
 
@@ -41,10 +40,6 @@ void launch_rvq_gather(hipStream_t st, int dtype, const float* table, const unsi
 // Epilogue of every conv GEMM: bias, optional tanh-GELU (ConvNeXt pwconv1, audio/tokenizer/v2/convnext.rs:81),
 // optional per-channel scale (ConvNeXt gamma), optional residual, then the raw result and/or its
 // SnakeBeta (audio/tokenizer/v2/snake_beta.rs:37-73: x + sin^2(x e^alpha) / (e^beta + 1e-9), in f32).
-__device__ __forceinline__ float gelu_tanh(float v) {
-    return 0.5f * v * (1.0f + tanhf(0.7978845608028654f * v * (1.0f + 0.044715f * v * v)));
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void conv_epilogue_kernel(ConvEpi e) {
     const long total = e.M * (long)e.N / 4;
@@ -54,51 +49,16 @@ __global__ __launch_bounds__(256) void conv_epilogue_kernel(ConvEpi e) {
         const long u = m / e.S_in;
         const int tp = (int)(m % e.S_in);
         if (tp >= e.lens[u]) continue;  // rows past the strip's last valid step only hold padding / the next strip
-        const int j = n / e.Cout, co = n % e.Cout;
-        const long orow = u * e.S_out + e.P_out + (long)tp * e.r + j;
         const float4 a = *reinterpret_cast<const float4*>(e.acc + m * e.N + n);
         float v[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float x = v[q] + (e.bias ? e.bias[co + q] : 0.f);
-            if (e.bias_u) x += e.bias_u[u * e.Cout + co + q];
-            if (e.act == 1) x = gelu_tanh(x);
-            else if (e.act >= 2) {
-                x = fmaxf(x, 0.f);
-                if (e.act == 3) x = tanhf(x);
-            }
-            if (e.scale) x = x * e.scale[co + q];
-            if (e.resid) x = to_f32<T>(((const T*)e.resid)[orow * e.ld_out + co + q]) + x;
-            if (e.resid_f32) x = e.resid_f32[orow * e.ld_out + co + q] + x;
-            v[q] = x;
-        }
-        if (e.Cvalid && co >= e.Cvalid) continue;  // columns past the layer's real width are padding
-        if (e.out) {
-            T* o = (T*)e.out + orow * e.ld_out + co;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(v[q]);
-        }
-        if (e.out_f32) {
-            float* o = e.out_f32 + orow * e.ld_out + co;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = v[q];
-        }
-        if (e.out2) {
-            T* o = (T*)e.out2 + orow * e.ld_out + co;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                // SnakeBeta in f32 on the value the next op would read: the stored (rounded) one unless an f32 copy is kept
-                const float x = e.out_f32 ? v[q] : to_f32<T>(from_f32<T>(v[q]));
-                const float sn = sinf(x * e.alpha_exp[co + q]);
-                o[q] = from_f32<T>(x + sn * sn / e.beta_den[co + q]);
-            }
-        }
+        conv_epi_apply<T>(e, u, tp, n, v);
     }
 }
 
 void launch_conv_epilogue(hipStream_t st, int dtype, const ConvEpi& e) {
     QTTS_CHECK(e.N % 4 == 0 && e.Cout % 4 == 0 && e.N == e.r * e.Cout && e.M >= 1 && e.Cvalid % 4 == 0, ERR_SHAPE, "conv_epilogue: bad shape");
     QTTS_CHECK(e.out2 == nullptr || (e.alpha_exp && e.beta_den), ERR_BAD_ARG, "conv_epilogue: snake output without parameters");
+    QTTS_CHECK(e.acc != nullptr, ERR_BAD_ARG, "conv_epilogue: GEMM output missing");
     const long total = e.M * (long)e.N / 4;
     const int blocks = (int)std::min<long>((total + 255) / 256, 8192);
     if (dtype == BF16) hipLaunchKernelGGL(conv_epilogue_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, e);
@@ -145,34 +105,56 @@ void launch_dwconv_ln(hipStream_t st, int dtype, const void* x, const float* w, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Final conv (C -> 1, k = 7, causal) + clamp[-1, 1] (decoder/v2.rs:238-246).  One wave per output sample group:
-// 4 lanes share a sample (each a quarter of the channels), 64 samples per block.
+// Final conv (C -> 1, k = 7, causal) + clamp[-1, 1] (decoder/v2.rs:238-246).  A block produces 64 consecutive samples:
+// their 70 input rows are staged in LDS with 16-byte loads (each row is shared by up to 7 samples), four lanes share a
+// sample (a quarter of the channels each).
 template <typename T>
 __global__ __launch_bounds__(256) void final_conv_kernel(const T* __restrict__ x, const float* __restrict__ w /*[7][C]*/, float bias,
                                                          const int* __restrict__ nvalid, long S, int P, int C, float* wav,
                                                          long wav_stride) {
+    extern __shared__ __align__(16) unsigned char smem[];
     const int u = blockIdx.y;
-    const long t = (long)blockIdx.x * 64 + (threadIdx.x >> 2);
-    const int part = threadIdx.x & 3;
-    const long n = nvalid[u];
+    const long t0 = (long)blockIdx.x * 64;
+    const int n = nvalid[u];
+    if (t0 >= n) return;
+    const int row_bytes = C * (int)sizeof(T), pitch = row_bytes + 16;  // +16: consecutive rows start 4 banks apart
+    const int vpr = row_bytes / 16;
+    float* wl = reinterpret_cast<float*>(smem + 70 * pitch);
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(x + ((long)u * S + P + t0 - 6) * C);
+    for (int v = threadIdx.x; v < 70 * vpr; v += 256) {
+        const int row = v / vpr, c16 = v % vpr;
+        *reinterpret_cast<uint4*>(smem + row * pitch + c16 * 16) = *reinterpret_cast<const uint4*>(src + (long)row * row_bytes + c16 * 16);
+    }
+    for (int i = threadIdx.x; i < 7 * C; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const int sidx = threadIdx.x >> 2, part = threadIdx.x & 3;
+    const int cq = C / 4, c0 = part * cq;
     float acc = 0.f;
-    if (t < n) {
-        const T* base = x + ((long)u * S + P + t - 6) * C;
-        const int c0 = part * (C / 4), c1 = c0 + C / 4;
-        for (int k = 0; k < 7; ++k)
-            for (int c = c0; c < c1; ++c) acc += to_f32<T>(base[(long)k * C + c]) * w[k * C + c];
+    for (int k = 0; k < 7; ++k) {
+        const T* row = reinterpret_cast<const T*>(smem + (sidx + k) * pitch) + c0;
+        const float* wk = wl + k * C + c0;
+        for (int c = 0; c < cq; c += 8) {
+            float xv[8];
+            load8(row + c, xv);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += xv[q] * wk[c + q];
+        }
     }
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
+    const long t = t0 + sidx;
     if (t < n && part == 0) wav[(long)u * wav_stride + t] = fminf(1.0f, fmaxf(-1.0f, acc + bias));
 }
 
 void launch_final_conv(hipStream_t st, int dtype, const void* x, const float* w, float bias, const int* nvalid, int U, long Tmax, long S,
                        int P, int C, float* wav, long wav_stride) {
-    QTTS_CHECK(P >= 6 && C % 4 == 0 && U >= 1 && Tmax >= 1, ERR_SHAPE, "final_conv: bad shape");
+    QTTS_CHECK(P >= 6 && C % 32 == 0 && U >= 1 && Tmax >= 1, ERR_SHAPE, "final_conv: needs six padding rows and a channel count that is a multiple of 32");
+    const size_t es = dtype == BF16 ? 2 : 4;
+    const size_t lds = 70 * ((size_t)C * es + 16) + (size_t)7 * C * 4;
+    QTTS_CHECK(lds <= 64 * 1024, ERR_SHAPE, "final_conv: too many channels for the LDS staging buffer");
     dim3 grid((unsigned)((Tmax + 63) / 64), U);
-    if (dtype == BF16) hipLaunchKernelGGL(final_conv_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, w, bias, nvalid, S, P, C, wav, wav_stride);
-    else hipLaunchKernelGGL(final_conv_kernel<float>, grid, dim3(256), 0, st, (const float*)x, w, bias, nvalid, S, P, C, wav, wav_stride);
+    if (dtype == BF16) hipLaunchKernelGGL(final_conv_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)x, w, bias, nvalid, S, P, C, wav, wav_stride);
+    else hipLaunchKernelGGL(final_conv_kernel<float>, grid, dim3(256), lds, st, (const float*)x, w, bias, nvalid, S, P, C, wav, wav_stride);
 }
 
 }  // namespace qtts

@@ -10,8 +10,7 @@
 // v_mfma_f32_16x16x32_bf16 (or the exact v_mfma_f32_16x16x4_f32 for f32 weights) with the W tile as
 // the A operand and the X tile as the B operand, so a lane ends up holding four consecutive n for
 // one m.  The four wave partials are summed through LDS in wave order (deterministic).
-#include "device_utils.hpp"
-#include "kernels.hpp"
+#include "conv_epi.hpp"
 #include <cstdlib>
 #include <algorithm>
 
@@ -236,10 +235,11 @@ static void launch_t(hipStream_t st, const T* W, const T* X, float* out, int Mpa
 // The X operand supports convolution addressing without im2col: with channels-last activations the
 // taps of a causal conv are row offsets, so chunk cg reads X[(m + (cg / cpt) * tap_rows)][(cg % cpt) * CHUNK ...]
 // (cpt = chunks per tap).  A plain linear layer is the single-tap case.
-template <typename T, int NT, int NCH>
+// With EPI the conv epilogue (conv_epi.hpp) runs on the accumulators in registers and no f32 output is written.
+template <typename T, int NT, int NCH, bool EPI>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(const T* __restrict__ W, const T* __restrict__ X,
                                                         float* __restrict__ out, int N, int K, int ldx, int cpt,
-                                                        long tap_stride, long row_base) {
+                                                        long tap_stride, long row_base, ConvEpi e) {
     using F = Frag<T>;
     constexpr int MT = 4;
     constexpr int HALF = 16 / sizeof(T);
@@ -286,6 +286,22 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const T* __restrict__ W,
         }
         __syncthreads();
     }
+    if (EPI) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const long m = row0 + 16 * i + r;
+            if (m >= e.M) continue;
+            const long u = m / e.S_in;
+            const int tp = (int)(m - u * e.S_in);
+            if (tp >= e.lens[u]) continue;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                conv_epi_apply<T>(e, u, tp, n0 + 16 * j + 4 * g, v);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -293,17 +309,18 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const T* __restrict__ W,
             *reinterpret_cast<f32x4_t*>(out + (size_t)(row0 - row_base + 16 * i + r) * N + n0 + 16 * j + 4 * g) = acc[i][j];
 }
 
-template <typename T>
-static void launch_rows_t(hipStream_t st, const T* W, const T* X, float* out, long Mpad, int N, int K, int ldx, int cpt, long tap_stride) {
+template <typename T, bool EPI>
+static void launch_rows_t(hipStream_t st, const T* W, const T* X, float* out, long Mpad, int N, int K, int ldx, int cpt, long tap_stride,
+                          const ConvEpi& e) {
     const int nC = K / Frag<T>::CHUNK;
     // out rows are relative to the launch: split launches at the grid.y limit
     for (long base = 0; base < Mpad; base += 65535L * 64) {
         const long rows = std::min<long>(Mpad - base, 65535L * 64);
-        float* o = out + (size_t)base * N;
+        float* o = EPI ? nullptr : out + (size_t)base * N;
         const int gy = (int)(rows / 64);
-#define QTTS_ROWS(nt, nch)                                                                                                     \
-    hipLaunchKernelGGL((gemm_rows_kernel<T, nt, nch>), dim3(N / (64 * nt), gy), dim3(256), 0, st, W, X, o, N, K, ldx, cpt, \
-                       tap_stride, base)
+#define QTTS_ROWS(nt, nch)                                                                                                          \
+    hipLaunchKernelGGL((gemm_rows_kernel<T, nt, nch, EPI>), dim3(N / (64 * nt), gy), dim3(256), 0, st, W, X, o, N, K, ldx, cpt, \
+                       tap_stride, base, e)
         if (N % 128 == 0) {
             if (nC % 4 == 0) QTTS_ROWS(2, 4);
             else if (nC % 2 == 0) QTTS_ROWS(2, 2);
@@ -325,8 +342,26 @@ void launch_gemm_rows(hipStream_t st, int dtype, const void* W, const void* X, f
     QTTS_CHECK((K / taps) % chunk == 0, ERR_SHAPE, "gemm_rows: channels per tap must be a multiple of the K chunk");
     const long Mpad = (M + 63) / 64 * 64;
     const int cpt = K / taps / chunk;
-    if (dtype == BF16) launch_rows_t<bf16_t>(st, (const bf16_t*)W, (const bf16_t*)X, out, Mpad, N, K, ldx, cpt, tap_stride);
-    else launch_rows_t<float>(st, (const float*)W, (const float*)X, out, Mpad, N, K, ldx, cpt, tap_stride);
+    const ConvEpi none{};
+    if (dtype == BF16) launch_rows_t<bf16_t, false>(st, (const bf16_t*)W, (const bf16_t*)X, out, Mpad, N, K, ldx, cpt, tap_stride, none);
+    else launch_rows_t<float, false>(st, (const float*)W, (const float*)X, out, Mpad, N, K, ldx, cpt, tap_stride, none);
+}
+
+// Same GEMM with the conv epilogue applied in registers (no f32 output): e.acc is ignored, e.M bounds the rows.
+void launch_gemm_rows_epi(hipStream_t st, int dtype, const void* W, const void* X, int K, int ldx, int taps, long tap_stride,
+                          const ConvEpi& e) {
+    const long M = e.M;
+    const int N = e.N;
+    QTTS_CHECK(M >= 1 && N % 64 == 0 && taps >= 1 && K % taps == 0, ERR_SHAPE, "gemm_rows: N must be a multiple of 64");
+    QTTS_CHECK(e.N % 4 == 0 && e.Cout % 4 == 0 && e.N == e.r * e.Cout && e.Cvalid % 4 == 0 && e.lens && e.S_in >= 1, ERR_SHAPE,
+               "gemm_rows: bad epilogue shape");
+    QTTS_CHECK(e.out2 == nullptr || (e.alpha_exp && e.beta_den), ERR_BAD_ARG, "gemm_rows: snake output without parameters");
+    const int chunk = dtype == BF16 ? 64 : 32;
+    QTTS_CHECK((K / taps) % chunk == 0, ERR_SHAPE, "gemm_rows: channels per tap must be a multiple of the K chunk");
+    const long Mpad = (M + 63) / 64 * 64;
+    const int cpt = K / taps / chunk;
+    if (dtype == BF16) launch_rows_t<bf16_t, true>(st, (const bf16_t*)W, (const bf16_t*)X, nullptr, Mpad, N, K, ldx, cpt, tap_stride, e);
+    else launch_rows_t<float, true>(st, (const float*)W, (const float*)X, nullptr, Mpad, N, K, ldx, cpt, tap_stride, e);
 }
 
 int gemm_pad_rows(int M) { return M <= 16 ? 16 : (M <= 32 ? 32 : (M + 63) / 64 * 64); }

@@ -183,6 +183,9 @@ struct ConvEpi {
     const float* beta_den;   // exp(beta) + 1e-9
 };
 void launch_conv_epilogue(hipStream_t st, int dtype, const ConvEpi& e);
+// GEMM + epilogue in one launch (k_gemm.hip): rows e.M, columns e.N; e.acc is not used
+void launch_gemm_rows_epi(hipStream_t st, int dtype, const void* W, const void* X, int K, int ldx, int taps, long tap_stride,
+                          const ConvEpi& e);
 void launch_rvq_gather(hipStream_t st, int dtype, const float* table, const unsigned* codes, const int* rows, const int* starts,
                        const int* lens, int U, int Tc, int Q, int csize, int Dc, int T_max, long S, int P, void* out, int ld);
 void launch_dwconv_ln(hipStream_t st, int dtype, const void* x, const float* w, const float* b, const float* ln_w, const float* ln_b,

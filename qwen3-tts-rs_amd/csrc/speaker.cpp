@@ -246,11 +246,12 @@ void run_speaker_embed(Model& m, const float* audio, const int* n_samples, int B
     s.emb.ensure((size_t)U * s.enc_dim * 4);
     float* acc = s.acc.as<float>();
     auto zero = [&](DevBuf& d, int C) { QTTS_HIP(hipMemsetAsync(d.p, 0, rows * (size_t)C * es, st)); };
-    auto epi = [&](const GemmW& g, int act, void* out, int ld_out, const float* bias_u = nullptr, int Cvalid = 0) {
+    // conv / linear as one launch: tap-addressed GEMM with bias + activation applied in registers
+    auto conv = [&](const GemmW& g, const void* X, int ldx, int act, void* out, int ld_out, const float* bias_u = nullptr, int Cvalid = 0) {
         ConvEpi e{};
-        e.acc = acc; e.M = M; e.N = g.N; e.r = 1; e.Cout = g.CoutP; e.bias = g.bias.p ? g.bias.as<float>() : nullptr; e.bias_u = bias_u;
+        e.M = M; e.N = g.N; e.r = 1; e.Cout = g.CoutP; e.bias = g.bias.p ? g.bias.as<float>() : nullptr; e.bias_u = bias_u;
         e.Cvalid = Cvalid; e.act = act; e.lens = d_len; e.S_in = S; e.S_out = S; e.P_out = P; e.ld_out = ld_out; e.out = out;
-        launch_conv_epilogue(st, dt, e);
+        launch_gemm_rows_epi(st, dt, g.w.p, X, g.K, ldx, g.taps, (long)g.dil * ldx, e);
     };
     auto at = [&](const DevBuf& d, long row, int ld) { return (const char*)d.p + (size_t)row * ld * es; };
 
@@ -260,10 +261,8 @@ void run_speaker_embed(Model& m, const float* audio, const int* n_samples, int B
                s.fbT.as<float>(), nullptr, 0, s.melT.p, S, P);
     if (s.pad0 > 0) launch_reflect_fill(st, dt, s.melT.p, d_len, U, S, P, s.pad0, NMEL);
     // blocks.0: TDNN k = 5 + ReLU
-    launch_gemm_rows(st, dt, s.block0.w.p, at(s.melT, P - s.pad0, NMEL), acc, M, s.block0.N, s.block0.K, NMEL, s.block0.taps,
-                     (long)s.block0.dil * NMEL);
     zero(s.h0, s.block0.CoutP);
-    epi(s.block0, 2, s.h0.p, s.block0.CoutP);
+    conv(s.block0, at(s.melT, P - s.pad0, NMEL), NMEL, 2, s.h0.p, s.block0.CoutP);
     // SE-Res2Net blocks; block i writes its output into channel slice i of `cat`
     zero(s.cat, s.catP);
     const void* hin = s.h0.p;
@@ -272,26 +271,19 @@ void run_speaker_embed(Model& m, const float* audio, const int* n_samples, int B
     for (size_t bi = 0; bi < s.blocks.size(); ++bi) {
         const SpeakerState::Block& blk = s.blocks[bi];
         // tdnn1 (1x1 + ReLU)
-        launch_gemm_rows(st, dt, blk.tdnn1.w.p, (const char*)hin + (size_t)P * ld_in * es, acc, M, blk.tdnn1.N, blk.tdnn1.K, ld_in, 1, 0);
         zero(s.a, blk.CP);
-        epi(blk.tdnn1, 2, s.a.p, blk.CP);
+        conv(blk.tdnn1, (const char*)hin + (size_t)P * ld_in * es, ld_in, 2, s.a.p, blk.CP);
         // Res2Net: chunk 0 passes through, chunk j = conv(chunk_j [+ out_{j-1}]) + ReLU
         zero(s.r, blk.CP);
         launch_slice_copy(st, dt, s.a.p, d_len, U, Tm, S, P, blk.CP, blk.cs, s.r.p);
         for (size_t j = 1; j <= blk.res.size(); ++j) {
             const GemmW& g = blk.res[j - 1];
             launch_res2net_prep(st, dt, s.a.p, j >= 2 ? s.r.p : nullptr, d_len, U, Tm, S, P, blk.pad, blk.CP, (int)j * blk.cs, blk.cs, s.tmp.p);
-            launch_gemm_rows(st, dt, g.w.p, at(s.tmp, P - blk.pad, 64), acc, M, g.N, g.K, 64, g.taps, (long)g.dil * 64);
-            ConvEpi e{};
-            e.acc = acc; e.M = M; e.N = g.N; e.r = 1; e.Cout = g.CoutP; e.bias = g.bias.as<float>(); e.Cvalid = blk.cs; e.act = 2;
-            e.lens = d_len; e.S_in = S; e.S_out = S; e.P_out = P; e.ld_out = blk.CP;
-            e.out = (char*)s.r.p + (size_t)j * blk.cs * es;
-            launch_conv_epilogue(st, dt, e);
+            conv(g, at(s.tmp, P - blk.pad, 64), 64, 2, (char*)s.r.p + (size_t)j * blk.cs * es, blk.CP, nullptr, blk.cs);
         }
         // tdnn2 (1x1 + ReLU)
-        launch_gemm_rows(st, dt, blk.tdnn2.w.p, at(s.r, P, blk.CP), acc, M, blk.tdnn2.N, blk.tdnn2.K, blk.CP, 1, 0);
         zero(s.t2, blk.CP);
-        epi(blk.tdnn2, 2, s.t2.p, blk.CP);
+        conv(blk.tdnn2, at(s.r, P, blk.CP), blk.CP, 2, s.t2.p, blk.CP);
         // squeeze-excitation: mean over time -> 1x1 + ReLU -> 1x1 + sigmoid -> scale, then the block residual
         launch_time_stats(st, dt, s.t2.p, blk.CP, nullptr, 0, nullptr, d_len, U, S, P, 0, blk.C, 0, s.vec1.as<float>());
         launch_small_fc(st, blk.se_w1.as<float>(), blk.C, blk.se_b1.as<float>(), s.vec1.as<float>(), blk.C, U, blk.se, blk.C, 2, s.vec2.as<float>(), blk.se);
@@ -304,21 +296,16 @@ void run_speaker_embed(Model& m, const float* audio, const int* n_samples, int B
         off += blk.CP;
     }
     // MFA: 1x1 TDNN over the concatenated block outputs
-    launch_gemm_rows(st, dt, s.mfa.w.p, at(s.cat, P, s.catP), acc, M, s.mfa.N, s.mfa.K, s.catP, 1, 0);
     zero(s.mm, s.CmP);
-    epi(s.mfa, 2, s.mm.p, s.CmP);
+    conv(s.mfa, at(s.cat, P, s.catP), s.catP, 2, s.mm.p, s.CmP);
     // attentive statistics pooling (lengths = None: every step of the clip counts)
     launch_time_stats(st, dt, s.mm.p, s.CmP, nullptr, 0, nullptr, d_len, U, S, P, 0, s.Cm, 1, s.vec1.as<float>());
     launch_small_fc(st, s.asp_wb.as<float>(), 2 * s.Cm, s.asp_b.as<float>(), s.vec1.as<float>(), 2 * s.Cm, U, s.Ca, 2 * s.Cm, 0, s.vec2.as<float>(),
                     s.CaP);
-    launch_gemm_rows(st, dt, s.asp_a.w.p, at(s.mm, P, s.CmP), acc, M, s.asp_a.N, s.asp_a.K, s.CmP, 1, 0);
     zero(s.att, s.CaP);
-    {
-        ConvEpi e{};
-        e.acc = acc; e.M = M; e.N = s.CaP; e.r = 1; e.Cout = s.CaP; e.bias_u = s.vec2.as<float>(); e.Cvalid = (s.Ca + 3) / 4 * 4; e.act = 3;
-        e.lens = d_len; e.S_in = S; e.S_out = S; e.P_out = P; e.ld_out = s.CaP; e.out = s.att.p;
-        launch_conv_epilogue(st, dt, e);
-    }
+    s.asp_a.taps = 1;
+    s.asp_a.dil = 1;
+    conv(s.asp_a, at(s.mm, P, s.CmP), s.CmP, 3, s.att.p, s.CaP, s.vec2.as<float>(), (s.Ca + 3) / 4 * 4);
     launch_gemm_rows(st, dt, s.asp_conv.w.p, at(s.att, P, s.CaP), acc, M, s.asp_conv.N, s.asp_conv.K, s.CaP, 1, 0);
     // softmax over time of (asp.conv output + bias), read straight from the GEMM output (its rows carry no leading padding)
     launch_time_stats(st, dt, s.mm.p, s.CmP, acc, s.asp_conv.N, s.asp_conv.bias.as<float>(), d_len, U, S, P, 0, s.Cm, 2, s.vec1.as<float>());
