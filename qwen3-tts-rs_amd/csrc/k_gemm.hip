@@ -162,6 +162,7 @@ __global__ __launch_bounds__(256) void gemm_ldsx_kernel(const T* __restrict__ W,
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's LDS DMA has landed before it signals the barrier
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const T* __restrict__ W,
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 a[c][j].load(W + (size_t)(n0 + 16 * j + r) * K + (size_t)(c0 + c) * F::CHUNK + g * F::EPL);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's LDS DMA has landed before it signals the barrier
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -323,10 +325,12 @@ static void launch_rows_t(hipStream_t st, const T* W, const T* X, float* out, lo
                        tap_stride, base, e)
         if (N % 128 == 0) {
             if (nC % 4 == 0) QTTS_ROWS(2, 4);
+            else if (nC % 3 == 0) QTTS_ROWS(2, 3);
             else if (nC % 2 == 0) QTTS_ROWS(2, 2);
             else QTTS_ROWS(2, 1);
         } else {
             if (nC % 4 == 0) QTTS_ROWS(1, 4);
+            else if (nC % 3 == 0) QTTS_ROWS(1, 3);
             else if (nC % 2 == 0) QTTS_ROWS(1, 2);
             else QTTS_ROWS(1, 1);
         }
