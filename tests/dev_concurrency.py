@@ -32,7 +32,7 @@ for B in (64, 32, 16):
     t0 = time.perf_counter(); run(models[0], reqs(B, 0), out, 0); t1 = time.perf_counter()
     print(f"single stream B={B}: {out[0]:.3f} ms/frame wall {t1 - t0:.3f}s", flush=True)
 for n in range(2, NM + 1):
-    B = 64 // n
+    B = int(os.environ.get("BPER", 64 // n))
     out = [0] * n
     for rep in range(2):
         th = [threading.Thread(target=run, args=(models[i], reqs(B, i * B), out, i)) for i in range(n)]
@@ -40,5 +40,5 @@ for n in range(2, NM + 1):
         for t in th: t.start()
         for t in th: t.join()
         t1 = time.perf_counter()
-    print(f"{n} concurrent streams x B={B}: per-stream ms/frame {['%.3f' % o for o in out]} wall {t1 - t0:.3f}s -> effective {1e3 * (t1 - t0) / FR:.3f} ms per 64-row frame", flush=True)
+    print(f"{n} concurrent streams x B={B}: per-stream ms/frame {['%.3f' % o for o in out]} wall {t1 - t0:.3f}s -> effective {1e3 * (t1 - t0) / FR / (n * B / 64):.3f} ms per 64-row frame", flush=True)
 for m in models: m.close()
