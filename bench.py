@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=375, help="frames generated per utterance (30 s of audio)")
     ap.add_argument("--greedy", action="store_true", help="CLI --greedy semantics instead of seeded sampling")
     ap.add_argument("--no-codec", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the decode frame kernel by kernel (counter collection cannot follow hipGraphs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=96)
     return ap.parse_args()
@@ -140,7 +141,7 @@ def main():
 
     def step(mod, record):
         t_s = time.perf_counter()
-        out = mod.generate(reqs, sampling, args.frames, use_graph=True)
+        out = mod.generate(reqs, sampling, args.frames, use_graph=not args.no_graph)
         wavs = [] if args.no_codec else mod.decode_output(out)
         if record:
             with lock:
