@@ -187,7 +187,7 @@ struct Geometry {
     size_t bytes(size_t es) const { return act_elems * es * 3 + (acc_elems + res_elems) * 4 + (size_t)U * (size_t)wav_max * 4; }
 };
 
-constexpr long SLACK_ROWS = 192;  // readable rows past the last strip: 64-row GEMM tile padding + tap offsets
+constexpr long SLACK_ROWS = CONV_HALO_SLACK + 64;  // readable rows past the last strip: 64-row GEMM tile padding + tap offsets
 
 Geometry make_geometry(const CodecCfg& c, const CodecState& s, int U, int Tm) {
     Geometry g;

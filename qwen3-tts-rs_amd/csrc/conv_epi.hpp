@@ -13,40 +13,94 @@ __device__ __forceinline__ float gelu_tanh(float v) {
     return 0.5f * v * (1.0f + tanhf(0.7978845608028654f * v * (1.0f + 0.044715f * v * v)));
 }
 
-// One float4 of GEMM output: row m of the GEMM row space (strip u = m / S_in, step tp = m % S_in), columns n .. n + 3.
+// sin for SnakeBeta.  f32 runs keep the full-precision routine (bit-closeness to the reference's libm); bf16 runs use the
+// hardware sine after an explicit reduction to [0, 1) revolutions - its ~1e-6 absolute error is far below bf16 rounding.
+template <typename T>
+__device__ __forceinline__ float snake_sin(float x);
+template <>
+__device__ __forceinline__ float snake_sin<float>(float x) { return sinf(x); }
+template <>
+__device__ __forceinline__ float snake_sin<bf16_t>(float x) {
+    const float rev = x * 0.15915494309189535f;
+    return __builtin_amdgcn_sinf(rev - floorf(rev));
+}
+template <typename T>
+__device__ __forceinline__ float snake_div(float a, float den);
+template <>
+__device__ __forceinline__ float snake_div<float>(float a, float den) { return a / den; }
+template <>
+__device__ __forceinline__ float snake_div<bf16_t>(float a, float den) { return a * __builtin_amdgcn_rcpf(den); }
+
+__device__ __forceinline__ void ld4(const float* p, float (&o)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+}
+
+// One float4 of GEMM output: row m of the GEMM row space (strip u = m / S_in, step tp = m % S_in), columns n .. n + 3
+// (n is a multiple of 4, so are Cout and every channel offset: all parameter vectors are read as float4).
 template <typename T>
 __device__ __forceinline__ void conv_epi_apply(const ConvEpi& e, long u, int tp, int n, float (&v)[4]) {
-    const int j = n / e.Cout, co = n % e.Cout;
+    int j = 0, co = n;
+    if (e.r != 1) { j = n / e.Cout; co = n - j * e.Cout; }
     const long orow = u * e.S_out + e.P_out + (long)tp * e.r + j;
+    const long o_off = orow * e.ld_out + co;
+    if (e.bias) {
+        float b[4];
+        ld4(e.bias + co, b);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float x = v[q] + (e.bias ? e.bias[co + q] : 0.f);
-        if (e.bias_u) x += e.bias_u[u * e.Cout + co + q];
-        if (e.act == 1) x = gelu_tanh(x);
-        else if (e.act >= 2) {
-            x = fmaxf(x, 0.f);
-            if (e.act == 3) x = tanhf(x);
+        for (int q = 0; q < 4; ++q) v[q] += b[q];
+    }
+    if (e.bias_u) {
+        float b[4];
+        ld4(e.bias_u + u * e.Cout + co, b);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += b[q];
+    }
+    if (e.act == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
+    } else if (e.act >= 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[q] = fmaxf(v[q], 0.f);
+            if (e.act == 3) v[q] = tanhf(v[q]);
         }
-        if (e.scale) x = x * e.scale[co + q];
-        if (e.resid) x = to_f32<T>(((const T*)e.resid)[orow * e.ld_out + co + q]) + x;
-        if (e.resid_f32) x = e.resid_f32[orow * e.ld_out + co + q] + x;
-        v[q] = x;
+    }
+    if (e.scale) {
+        float sc[4];
+        ld4(e.scale + co, sc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = v[q] * sc[q];
+    }
+    if (e.resid) {
+        const T* rp = (const T*)e.resid + o_off;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = to_f32<T>(rp[q]) + v[q];
+    }
+    if (e.resid_f32) {
+        float rr[4];
+        ld4(e.resid_f32 + o_off, rr);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = rr[q] + v[q];
     }
     if (e.Cvalid && co >= e.Cvalid) return;  // columns past the layer's real width are padding
     if (e.out) {
-        T* o = (T*)e.out + orow * e.ld_out + co;
+        T* o = (T*)e.out + o_off;
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(v[q]);
     }
-    if (e.out_f32) *reinterpret_cast<float4*>(e.out_f32 + orow * e.ld_out + co) = make_float4(v[0], v[1], v[2], v[3]);
+    if (e.out_f32) *reinterpret_cast<float4*>(e.out_f32 + o_off) = make_float4(v[0], v[1], v[2], v[3]);
     if (e.out2) {
-        T* o = (T*)e.out2 + orow * e.ld_out + co;
+        float al[4], den[4];
+        ld4(e.alpha_exp + co, al);
+        ld4(e.beta_den + co, den);
+        T* o = (T*)e.out2 + o_off;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             // SnakeBeta in f32 on the value the next op would read: the stored (rounded) one unless an f32 copy is kept
             const float x = e.out_f32 ? v[q] : to_f32<T>(from_f32<T>(v[q]));
-            const float sn = sinf(x * e.alpha_exp[co + q]);
-            o[q] = from_f32<T>(x + sn * sn / e.beta_den[co + q]);
+            const float sn = snake_sin<T>(x * al[q]);
+            o[q] = from_f32<T>(x + snake_div<T>(sn * sn, den[q]));
         }
     }
 }

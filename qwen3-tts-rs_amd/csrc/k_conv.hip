@@ -1,0 +1,193 @@
+// Causal / transposed convolutions of the codec vocoder as implicit GEMM with the input tile held in LDS
+// (qwen_tts/src/audio/tokenizer/v2/causal_conv.rs:15-176, audio/decoder/residual_unit.rs:11-96).
+//
+// With channels-last strips the taps of a conv are row offsets, so a block that owns 16*MT consecutive output rows
+// needs input rows [m0, m0 + 16*MT + (taps-1)*dil): they are loaded ONCE into LDS (16-byte vectors, XOR-swizzled so that
+// the MFMA B-fragment reads of 16 consecutive rows hit distinct banks) and every tap reads them at its own row offset.
+// After that single barrier the K loop only streams weight fragments (L2-resident, four chunks in flight per wave) into
+// MFMAs; the element-wise tail of the layer (conv_epi.hpp) runs on the accumulators after a transpose through LDS that makes
+// its global accesses contiguous.  Compared with the generic
+// tap-addressed GEMM this removes the 7-fold re-read of the input and the per-phase barriers.
+#include "conv_epi.hpp"
+#include <algorithm>
+
+namespace qtts {
+
+namespace {
+
+template <typename T>
+struct CFrag;
+template <>
+struct CFrag<bf16_t> {
+    static constexpr int CHUNK = 64, EPL = 16;
+    bf16x8_t v[2];
+    __device__ __forceinline__ void load(const bf16_t* p) {
+        v[0] = *reinterpret_cast<const bf16x8_t*>(p);
+        v[1] = *reinterpret_cast<const bf16x8_t*>(p + 8);
+    }
+    static __device__ __forceinline__ f32x4_t mma(const CFrag& a, const CFrag& b, f32x4_t c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v[0], b.v[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v[1], b.v[1], c, 0, 0, 0);
+        return c;
+    }
+};
+template <>
+struct CFrag<float> {
+    static constexpr int CHUNK = 32, EPL = 8;
+    float v[8];
+    __device__ __forceinline__ void load(const float* p) {
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        const float4 b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ f32x4_t mma(const CFrag& a, const CFrag& b, f32x4_t c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
+        return c;
+    }
+};
+
+template <typename T, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W, const T* __restrict__ X, int K, int C, int taps, int dil,
+                                                        ConvEpi e) {
+    using F = CFrag<T>;
+    extern __shared__ uint4 tile[];
+    constexpr int RT = 16 * MT;
+    constexpr int VPE = 16 / (int)sizeof(T);  // elements per 16-byte vector
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const long m0 = (long)blockIdx.y * RT;
+    const int vpr = C / VPE;  // vectors per row (a multiple of 8)
+    const int rows_t = RT + (taps - 1) * dil;
+    {
+        const T* src = X + m0 * C;
+        for (int v = threadIdx.x; v < rows_t * vpr; v += 256) {
+            const int row = v / vpr, col = v - row * vpr;
+            tile[row * vpr + (col ^ (row & 7))] = *reinterpret_cast<const uint4*>(src + (long)row * C + col * VPE);
+        }
+    }
+    const int n0 = blockIdx.x * (64 * NT) + wave * (16 * NT);
+    const int cpt = C / F::CHUNK, nC = taps * cpt;
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    constexpr int PF = MT * NT >= 12 ? 2 : 4;  // weight chunks in flight per wave (register budget)
+    F a[PF][NT];
+    const T* wrow[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wrow[j] = W + (size_t)(n0 + 16 * j + r) * K + g * F::EPL;
+#pragma unroll
+    for (int s = 0; s < PF - 1; ++s)
+        if (s < nC) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) a[s][j].load(wrow[j] + (size_t)s * F::CHUNK);
+        }
+    __syncthreads();
+    for (int q0 = 0; q0 < nC; q0 += PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            const int q = q0 + s;
+            if (q + PF - 1 < nC) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) a[(s + PF - 1) % PF][j].load(wrow[j] + (size_t)(q + PF - 1) * F::CHUNK);
+            }
+            if (q < nC) {
+                const int tap = q / cpt, c = q - tap * cpt;
+                const int vb = (c * F::CHUNK + g * F::EPL) / VPE;  // first of the two 16-byte vectors of this lane's fragment
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int row = 16 * i + r + tap * dil;
+                    const uint4 h0 = tile[row * vpr + (vb ^ (row & 7))];
+                    const uint4 h1 = tile[row * vpr + ((vb + 1) ^ (row & 7))];
+                    F b;
+                    __builtin_memcpy(&b, &h0, 16);
+                    __builtin_memcpy((char*)&b + 16, &h1, 16);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[s][j], b, acc[i][j]);
+                }
+            }
+        }
+    }
+    // Epilogue through LDS: the accumulators (a lane holds 4 columns of one row, 16 rows per wave) are transposed so that
+    // consecutive lanes own consecutive columns of the same row and every global access of the tail is a full contiguous run.
+    constexpr int COLS = 64 * NT, OP = COLS + 4;  // padded f32 row pitch
+    float* otile = reinterpret_cast<float*>(tile);
+    __shared__ int row_u[RT], row_tp[RT];  // strip and step of every tile row (tp < 0: row holds no output)
+    __syncthreads();  // every wave is done reading the input tile
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            *reinterpret_cast<f32x4_t*>(otile + (16 * i + r) * OP + wave * (16 * NT) + 16 * j + 4 * g) = acc[i][j];
+    if ((int)threadIdx.x < RT) {
+        const long m = m0 + threadIdx.x;
+        int uu = 0, tt = -1;
+        if (m < e.M) {
+            const long u = m / e.S_in;
+            const int tp = (int)(m - u * e.S_in);
+            uu = (int)u;
+            tt = tp < e.lens[u] ? tp : -1;
+        }
+        row_u[threadIdx.x] = uu;
+        row_tp[threadIdx.x] = tt;
+    }
+    __syncthreads();
+    constexpr int GPR = COLS / 4;
+    for (int idx = threadIdx.x; idx < RT * GPR; idx += 256) {
+        const int row = idx / GPR, c4 = idx - row * GPR;
+        const int tp = row_tp[row];
+        if (tp < 0) continue;
+        const long u = row_u[row];
+        const float4 a4 = *reinterpret_cast<const float4*>(otile + row * OP + 4 * c4);
+        float v[4] = {a4.x, a4.y, a4.z, a4.w};
+        conv_epi_apply<T>(e, u, tp, blockIdx.x * COLS + 4 * c4, v);
+    }
+}
+
+template <typename T, int MT, int NT>
+void launch_halo(hipStream_t st, const T* W, const T* X, int K, int C, int taps, int dil, const ConvEpi& e, size_t lds) {
+    const long RT = 16 * MT;
+    const long gy = (e.M + RT - 1) / RT;
+    hipLaunchKernelGGL((conv_halo_kernel<T, MT, NT>), dim3(e.N / (64 * NT), (unsigned)gy), dim3(256), lds, st, W, X, K, C, taps, dil, e);
+}
+
+template <typename T>
+bool try_halo(hipStream_t st, const T* W, const T* X, int K, int C, int taps, int dil, const ConvEpi& e) {
+    // 64-row x 128-column tiles when N allows (a block then owns whole 256-byte runs of every output row), else
+    // 128-row x 64-column tiles once there are enough of them; wider per-wave tiles would push the accumulators past
+    // what the compiler keeps in registers.
+    const size_t row_bytes = (size_t)C * sizeof(T);
+    const size_t halo = (size_t)(taps - 1) * dil;
+    constexpr size_t LDS_MAX = 64 * 1024;
+    const bool wide = e.N % 128 == 0;
+    const bool tall = !wide && e.M >= 128L * 512 && (128 + halo) * row_bytes <= LDS_MAX;
+    const int rows = tall ? 128 : 64, cols = wide ? 128 : 64;
+    const size_t lds = std::max((rows + halo) * row_bytes, (size_t)rows * (cols + 4) * 4);
+    if (lds > LDS_MAX) return false;
+    const long gy = (e.M + rows - 1) / rows;
+    if (gy > 0x7fffffffL) return false;
+    if (wide) launch_halo<T, 4, 2>(st, W, X, K, C, taps, dil, e, lds);
+    else if (tall) launch_halo<T, 8, 1>(st, W, X, K, C, taps, dil, e, lds);
+    else launch_halo<T, 4, 1>(st, W, X, K, C, taps, dil, e, lds);
+    return true;
+}
+
+}  // namespace
+
+// Returns false when the shape does not fit the LDS-tile kernel (the caller then uses the tap-addressed GEMM).
+// X rows must be contiguous (row stride == channels per tap) and readable for 128 rows + the halo past e.M.
+bool launch_conv_halo(hipStream_t st, int dtype, const void* W, const void* X, int K, int ldx, int taps, long tap_stride, const ConvEpi& e) {
+    if (taps < 1 || K % taps != 0) return false;
+    const int C = K / taps;
+    const int chunk = dtype == BF16 ? 64 : 32;
+    if (C != ldx || C % 64 != 0 || C % chunk != 0 || e.N % 64 != 0) return false;
+    if (taps > 1 && (tap_stride <= 0 || tap_stride % ldx != 0)) return false;
+    const long dil = taps > 1 ? tap_stride / ldx : 1;
+    if (dil < 1 || dil > 64) return false;
+    if (dtype == BF16) return try_halo<bf16_t>(st, (const bf16_t*)W, (const bf16_t*)X, K, C, taps, (int)dil, e);
+    return try_halo<float>(st, (const float*)W, (const float*)X, K, C, taps, (int)dil, e);
+}
+
+}  // namespace qtts

@@ -362,6 +362,8 @@ void launch_gemm_rows_epi(hipStream_t st, int dtype, const void* W, const void* 
     QTTS_CHECK(e.out2 == nullptr || (e.alpha_exp && e.beta_den), ERR_BAD_ARG, "gemm_rows: snake output without parameters");
     const int chunk = dtype == BF16 ? 64 : 32;
     QTTS_CHECK((K / taps) % chunk == 0, ERR_SHAPE, "gemm_rows: channels per tap must be a multiple of the K chunk");
+    static const bool halo_off = getenv("QTTS_CONV_HALO") && atoi(getenv("QTTS_CONV_HALO")) == 0;
+    if (!halo_off && launch_conv_halo(st, dtype, W, X, K, ldx, taps, tap_stride, e)) return;
     const long Mpad = (M + 63) / 64 * 64;
     const int cpt = K / taps / chunk;
     if (dtype == BF16) launch_rows_t<bf16_t, true>(st, (const bf16_t*)W, (const bf16_t*)X, nullptr, Mpad, N, K, ldx, cpt, tap_stride, e);

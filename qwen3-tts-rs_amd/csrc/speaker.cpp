@@ -14,7 +14,7 @@ namespace qtts {
 
 namespace {
 constexpr int NFFT = 1024, HOP = 256, NMEL = 128, NBIN = NFFT / 2 + 1, MELPAD = (NFFT - HOP) / 2;
-constexpr long SLACK = 192;
+constexpr long SLACK = CONV_HALO_SLACK + 64;
 
 // create_mel_filterbank (audio/mel.rs:236-327): Slaney mel scale, f64 construction, f32 storage, area normalisation
 std::vector<float> mel_filterbank_T(int sample_rate, double fmin, double fmax) {
