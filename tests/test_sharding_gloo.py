@@ -75,3 +75,34 @@ def test_two_rank_sharding_matches_single_process(bind):
     for i in range(5):
         ref = o.generate(synth.synthetic_text_ids(tmpl, 9 + 2 * i, i), prefill, GREEDY, 4, speaker_token=spk)["codes"]
         assert np.array_equal(ref, gathered[i])
+
+
+def _reduce_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    q.put((rank, bench.reduce_job(1.0 + rank, 10.0 * (rank + 1), dist, "cpu")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_bench_aggregates_max_time_and_total_audio():
+    """bench.py's only collective: value = audio seconds of ALL ranks / the SLOWEST rank's time."""
+    import torch.multiprocessing as mp
+    import bench
+    assert bench.reduce_job(2.0, 5.0, None, "cpu") == (2.0, 5.0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reduce_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=90) for _ in procs)
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == (2.0, 30.0)
