@@ -58,6 +58,58 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
     *reinterpret_cast<uint4*>(p) = o;
 }
 
+// Sum of KS split-K partial slabs (element p[k * stride]) in slab order, with the loads of up to four slabs in flight
+// at once (a plain loop serialises one memory round trip per slab).  The add order is the same as the plain loop's.
+__device__ __forceinline__ float4 slab_sum4(const float* p, int KS, long stride) {
+    float4 s = *reinterpret_cast<const float4*>(p);
+    int k = 1;
+    for (; k + 4 <= KS; k += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(p + (long)k * stride);
+        const float4 b = *reinterpret_cast<const float4*>(p + (long)(k + 1) * stride);
+        const float4 c = *reinterpret_cast<const float4*>(p + (long)(k + 2) * stride);
+        const float4 d = *reinterpret_cast<const float4*>(p + (long)(k + 3) * stride);
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+        s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+        s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+    }
+    if (k + 2 <= KS) {
+        const float4 a = *reinterpret_cast<const float4*>(p + (long)k * stride);
+        const float4 b = *reinterpret_cast<const float4*>(p + (long)(k + 1) * stride);
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+        k += 2;
+    }
+    if (k < KS) {
+        const float4 a = *reinterpret_cast<const float4*>(p + (long)k * stride);
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    return s;
+}
+// same for two scalars `gap` elements apart (a rotation pair of one head)
+__device__ __forceinline__ void slab_sum_pair(const float* p, int gap, int KS, long stride, float& x1, float& x2) {
+    float a1 = 0.f, a2 = 0.f;
+    int k = 0;
+    for (; k + 4 <= KS; k += 4) {
+        const float* q0 = p + (long)k * stride;
+        const float* q1 = q0 + stride;
+        const float* q2 = q1 + stride;
+        const float* q3 = q2 + stride;
+        const float u0 = q0[0], v0 = q0[gap], u1 = q1[0], v1 = q1[gap], u2 = q2[0], v2 = q2[gap], u3 = q3[0], v3 = q3[gap];
+        a1 += u0; a2 += v0;
+        a1 += u1; a2 += v1;
+        a1 += u2; a2 += v2;
+        a1 += u3; a2 += v3;
+    }
+    for (; k < KS; ++k) {
+        const float* q = p + (long)k * stride;
+        a1 += q[0];
+        a2 += q[gap];
+    }
+    x1 = a1;
+    x2 = a2;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -17,7 +17,7 @@ namespace {
 
 constexpr int PAGE_TOKENS = 64;      // talker KV page (positions per page)
 constexpr int CP_PAGE_TOKENS = 64;   // one page holds a whole code-predictor context (<= groups + 1)
-constexpr int PREFILL_CHUNK = 256;   // prompt tokens per prefill pass
+constexpr int PREFILL_CHUNK = 1024;   // prompt tokens per prefill pass
 constexpr int EOS_POLL = 8;          // frames between host checks of the EOS flags
 
 struct HostMT {  // MT19937 (rand_mt `Mt::new(seed as u32)`), 24-bit uniforms (nn/mt_rng.rs:64-81)
@@ -233,7 +233,8 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
                                2 * c.cp.inter, V, Vc, H, Ht, Hc});
     g.ws.x.ensure(rows * Wmax * 4);
     g.ws.xn.ensure(rows * Wmax * es);
-    g.ws.part.ensure(rows * (size_t)Nmax * 4 * 16);  // up to 16 split-K slabs
+    // up to 16 split-K slabs for the small-M kernels (at most 128 + 64 rows); the large-M kernel writes one [rows][N] matrix
+    g.ws.part.ensure(std::max(rows, (size_t)16 * std::min<size_t>(rows, 192)) * (size_t)Nmax * 4);
     g.ws.q.ensure(rows * QD * 4);
     g.ws.attn.ensure(rows * QD * es);
     g.ws.act.ensure(rows * Imax * es);

@@ -28,12 +28,8 @@ __global__ __launch_bounds__(64) void qkv_post_kernel(QkvPostArgs a, KVView kv) 
     const bool act = lane < half;
     const int i = act ? lane : 0;
     const long col = (long)hi * d + i;
-    float x1 = 0.f, x2 = 0.f;
-    for (int k = 0; k < a.KS; ++k) {
-        const float* p = a.part + k * a.ks_stride + (long)m * ncol + col;
-        x1 += p[0];
-        x2 += p[half];
-    }
+    float x1, x2;
+    slab_sum_pair(a.part + (long)m * ncol + col, half, a.KS, a.ks_stride, x1, x2);
     if (a.bias) {
         x1 += a.bias[col];
         x2 += a.bias[col + half];
@@ -183,12 +179,8 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KV
         const bool act = lane < HALF;
         const int i = act ? lane : 0;
         const long col = (long)head * D + i;
-        float x1 = 0.f, x2 = 0.f;
-        for (int k = 0; k < a.KS; ++k) {
-            const float* p = a.part + k * a.ks_stride + (long)m * ncol + col;
-            x1 += p[0];
-            x2 += p[HALF];
-        }
+        float x1, x2;
+        slab_sum_pair(a.part + (long)m * ncol + col, HALF, a.KS, a.ks_stride, x1, x2);
         if (a.bias) {
             x1 += a.bias[col];
             x2 += a.bias[col + HALF];

@@ -31,11 +31,7 @@ __device__ __forceinline__ float4 resid_combine(const float* __restrict__ resid,
                                                 const float* __restrict__ bias, const float* __restrict__ scale, long off, int i) {
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (part) {
-        s = *reinterpret_cast<const float4*>(part + off);
-        for (int k = 1; k < KS; ++k) {
-            const float4 p = *reinterpret_cast<const float4*>(part + k * ks_stride + off);
-            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
-        }
+        s = slab_sum4(part + off, KS, ks_stride);
     }
     if (bias) {
         const float4 b = *reinterpret_cast<const float4*>(bias + i);
@@ -123,14 +119,8 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const float* __restrict__ p
         const long row = (e * 4) / I;
         const int i = (int)((e * 4) % I);
         const float* pg = part + row * 2 * I + i;
-        float4 g = *reinterpret_cast<const float4*>(pg);
-        float4 u = *reinterpret_cast<const float4*>(pg + I);
-        for (int k = 1; k < KS; ++k) {
-            const float4 g2 = *reinterpret_cast<const float4*>(pg + k * ks_stride);
-            const float4 u2 = *reinterpret_cast<const float4*>(pg + k * ks_stride + I);
-            g.x += g2.x; g.y += g2.y; g.z += g2.z; g.w += g2.w;
-            u.x += u2.x; u.y += u2.y; u.z += u2.z; u.w += u2.w;
-        }
+        const float4 g = slab_sum4(pg, KS, ks_stride);
+        const float4 u = slab_sum4(pg + I, KS, ks_stride);
         T* o = act + row * I + i;
         o[0] = from_f32<T>(g.x / (1.0f + expf(-g.x)) * u.x);
         o[1] = from_f32<T>(g.y / (1.0f + expf(-g.y)) * u.y);
