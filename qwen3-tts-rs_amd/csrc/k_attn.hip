@@ -224,34 +224,59 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KV
         mx[h] = -1e30f;
         l[h] = 0.f;
     }
-    for (int base = wave * KPW; base < t.ctx_len; base += 4 * KPW) {
-        const int key = base + gi;
-        const bool valid = key < t.ctx_len;
-        const bool own = key == t.ctx_len - 1;
-        const int pos = t.ctx_start + (valid ? key : 0);
-        float kf[8], vf[8];
-        if (own) {
+    // The key loop is software-pipelined by hand: a fetch covers NG groups of KPW keys per wave, and the K/V rows (with the
+    // page-table entries in front of them) of the next fetch are in flight while the current one goes through the online softmax.
+    constexpr int NG = 2;
+    auto fetch = [&](int base, float(&kf)[NG][8], float(&vf)[NG][8]) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { kf[e] = kown[li * 8 + e]; vf[e] = vown[li * 8 + e]; }
-        } else {
-            load8(kv_ptr<T>(kv, a.layer, t.row, pos, 0, g) + li * 8, kf);
-            load8(kv_ptr<T>(kv, a.layer, t.row, pos, 1, g) + li * 8, vf);
+        for (int n = 0; n < NG; ++n) {
+            const int key = base + n * KPW + gi;
+            const bool valid = key < t.ctx_len;
+            if (key == t.ctx_len - 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { kf[n][e] = kown[li * 8 + e]; vf[n][e] = vown[li * 8 + e]; }
+            } else {
+                const int pos = t.ctx_start + (valid ? key : 0);
+                load8(kv_ptr<T>(kv, a.layer, t.row, pos, 0, g) + li * 8, kf[n]);
+                load8(kv_ptr<T>(kv, a.layer, t.row, pos, 1, g) + li * 8, vf[n]);
+            }
         }
+    };
+    auto accumulate = [&](int base, const float(&kf)[NG][8], const float(&vf)[NG][8]) {
 #pragma unroll
-        for (int h = 0; h < REP; ++h) {
-            float s = 0.f;
+        for (int n = 0; n < NG; ++n) {
+            const bool valid = base + n * KPW + gi < t.ctx_len;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += qv[h][e] * kf[e];
+            for (int h = 0; h < REP; ++h) {
+                float s = 0.f;
 #pragma unroll
-            for (int off = LPK / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-            s = valid ? s * scale : -INFINITY;
-            const float mn = fmaxf(mx[h], s);
-            const float alpha = expf(mx[h] - mn);
-            const float p = expf(s - mn);
-            l[h] = l[h] * alpha + p;
+                for (int e = 0; e < 8; ++e) s += qv[h][e] * kf[n][e];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[h][e] = o[h][e] * alpha + p * vf[e];
-            mx[h] = mn;
+                for (int off = LPK / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+                s = valid ? s * scale : -INFINITY;
+                const float mn = fmaxf(mx[h], s);
+                const float alpha = expf(mx[h] - mn);
+                const float p = expf(s - mn);
+                l[h] = l[h] * alpha + p;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[h][e] = o[h][e] * alpha + p * vf[n][e];
+                mx[h] = mn;
+            }
+        }
+    };
+    {
+        constexpr int STEP = 4 * NG * KPW;
+        float kA[NG][8], vA[NG][8], kB[NG][8], vB[NG][8];
+        int base = wave * NG * KPW;
+        if (base < t.ctx_len) fetch(base, kA, vA);
+        while (base < t.ctx_len) {
+            if (base + STEP < t.ctx_len) fetch(base + STEP, kB, vB);
+            accumulate(base, kA, vA);
+            base += STEP;
+            if (base >= t.ctx_len) break;
+            if (base + STEP < t.ctx_len) fetch(base + STEP, kA, vA);
+            accumulate(base, kB, vB);
+            base += STEP;
         }
     }
 #pragma unroll

@@ -221,22 +221,42 @@ __global__ __launch_bounds__(256) void embed_sum_norm_kernel(EmbedSumArgs a, con
     __syncthreads();
     const float* add = step < a.trailing_len[b] ? a.trailing + ((long)b * a.Tt_max + step) * a.H : a.tts_pad;
     float ss = 0.f;
-    for (int i = threadIdx.x; i < a.H; i += blockDim.x) {
-        float v = to_f32<TE>(rowp[0][i]);
+    // eight consecutive elements per thread: one 16-byte gather per codebook, eight codebooks in flight, adds in codebook order
+    for (int i = threadIdx.x * 8; i < a.H; i += blockDim.x * 8) {
+        float v[8];
+        load8(rowp[0] + i, v);
         int g = 1;
-        for (; g + 4 <= a.G; g += 4) {  // four gathers in flight; the adds stay in codebook order
-            const float e0 = to_f32<TE>(rowp[g][i]), e1 = to_f32<TE>(rowp[g + 1][i]), e2 = to_f32<TE>(rowp[g + 2][i]),
-                        e3 = to_f32<TE>(rowp[g + 3][i]);
-            v = v + e0;
-            v = v + e1;
-            v = v + e2;
-            v = v + e3;
+        for (; g + 8 <= a.G; g += 8) {
+            float e[8][8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) load8(rowp[g + u] + i, e[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = v[q] + e[u][q];
         }
-        for (; g < a.G; ++g) v = v + to_f32<TE>(rowp[g][i]);
-        v = v + add[i];
-        resid_out[(long)b * a.H + i] = v;
-        if (ss_out) xn[(long)b * a.H + i] = from_f32<T>(v * norm_w[i]);  // split norm: 1/rms is applied by the consuming GEMM
-        ss += v * v;
+        for (; g < a.G; ++g) {
+            float e[8];
+            load8(rowp[g] + i, e);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = v[q] + e[q];
+        }
+        float t8[8];
+        load8(add + i, t8);
+        float nw[8];
+        if (ss_out) load8(norm_w + i, nw);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            v[q] = v[q] + t8[q];
+            ss += v[q] * v[q];
+        }
+        store8(resid_out + (long)b * a.H + i, v);
+        if (ss_out) {  // split norm: 1/rms is applied by the consuming GEMM
+            float y[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) y[q] = v[q] * nw[q];
+            store8(xn + (long)b * a.H + i, y);
+        }
     }
     if (ss_out) {
         const float tot = block_sum(ss, red);
@@ -248,7 +268,7 @@ __global__ __launch_bounds__(256) void embed_sum_norm_kernel(EmbedSumArgs a, con
 
 void launch_embed_sum_norm(hipStream_t st, int dtype, const EmbedSumArgs& a, const float* norm_w, float eps, float* resid_out,
                            void* xn, float* ss_out) {
-    QTTS_CHECK(a.B >= 1 && a.H % 4 == 0 && a.G >= 1 && a.G <= 64, ERR_SHAPE, "embed_sum: bad shape");
+    QTTS_CHECK(a.B >= 1 && a.H % 8 == 0 && a.G >= 1 && a.G <= 64, ERR_SHAPE, "embed_sum: bad shape");
     if (a.edtype == BF16 && dtype == BF16) hipLaunchKernelGGL((embed_sum_norm_kernel<bf16_t, bf16_t>), dim3(a.B), dim3(256), 0, st, a, norm_w, eps, resid_out, (bf16_t*)xn, ss_out);
     else if (a.edtype == F32 && dtype == F32) hipLaunchKernelGGL((embed_sum_norm_kernel<float, float>), dim3(a.B), dim3(256), 0, st, a, norm_w, eps, resid_out, (float*)xn, ss_out);
     else throw Error(ERR_BAD_ARG, "embed_sum: embedding and activation dtypes must match");
