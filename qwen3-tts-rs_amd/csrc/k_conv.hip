@@ -10,6 +10,7 @@
 // tap-addressed GEMM this removes the 7-fold re-read of the input and the per-phase barriers.
 #include "conv_epi.hpp"
 #include <algorithm>
+#include <cstdlib>
 
 namespace qtts {
 
@@ -66,7 +67,9 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
             tile[row * vpr + (col ^ (row & 7))] = *reinterpret_cast<const uint4*>(src + (long)row * C + col * VPE);
         }
     }
-    const int n0 = blockIdx.x * (64 * NT) + wave * (16 * NT);
+    // wave w owns the 16-column tiles 4 j + w of the block's 64 NT columns (interleaved, so that an epilogue pass over
+    // tiles j .. j + PT - 1 of every wave covers one contiguous run of columns)
+    const int nb = blockIdx.x * (64 * NT);
     const int cpt = C / F::CHUNK, nC = taps * cpt;
     f32x4_t acc[MT][NT];
 #pragma unroll
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
     F a[PF][NT];
     const T* wrow[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) wrow[j] = W + (size_t)(n0 + 16 * j + r) * K + g * F::EPL;
+    for (int j = 0; j < NT; ++j) wrow[j] = W + (size_t)(nb + (4 * j + wave) * 16 + r) * K + g * F::EPL;
 #pragma unroll
     for (int s = 0; s < PF - 1; ++s)
         if (s < nC) {
@@ -112,15 +115,12 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
     }
     // Epilogue through LDS: the accumulators (a lane holds 4 columns of one row, 16 rows per wave) are transposed so that
     // consecutive lanes own consecutive columns of the same row and every global access of the tail is a full contiguous run.
-    constexpr int COLS = 64 * NT, OP = COLS + 4;  // padded f32 row pitch
+    // PT column tiles per wave go through the (re-used) LDS tile per pass, so that the staging buffer stays near 34 KB.
+    constexpr int PT = (MT >= 8 || NT == 1) ? 1 : 2;
+    constexpr int CP = 64 * PT, OP = CP + 4;  // columns per pass, padded f32 row pitch
+    static_assert(NT % PT == 0, "column tiles per wave must be a multiple of the tiles per epilogue pass");
     float* otile = reinterpret_cast<float*>(tile);
     __shared__ int row_u[RT], row_tp[RT];  // strip and step of every tile row (tp < 0: row holds no output)
-    __syncthreads();  // every wave is done reading the input tile
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-            *reinterpret_cast<f32x4_t*>(otile + (16 * i + r) * OP + wave * (16 * NT) + 16 * j + 4 * g) = acc[i][j];
     if ((int)threadIdx.x < RT) {
         const long m = m0 + threadIdx.x;
         int uu = 0, tt = -1;
@@ -133,16 +133,25 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
         row_u[threadIdx.x] = uu;
         row_tp[threadIdx.x] = tt;
     }
-    __syncthreads();
-    constexpr int GPR = COLS / 4;
-    for (int idx = threadIdx.x; idx < RT * GPR; idx += 256) {
-        const int row = idx / GPR, c4 = idx - row * GPR;
-        const int tp = row_tp[row];
-        if (tp < 0) continue;
-        const long u = row_u[row];
-        const float4 a4 = *reinterpret_cast<const float4*>(otile + row * OP + 4 * c4);
-        float v[4] = {a4.x, a4.y, a4.z, a4.w};
-        conv_epi_apply<T>(e, u, tp, blockIdx.x * COLS + 4 * c4, v);
+#pragma unroll
+    for (int p = 0; p < NT / PT; ++p) {
+        __syncthreads();  // the input tile / the previous pass is no longer read
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int jj = 0; jj < PT; ++jj)
+                *reinterpret_cast<f32x4_t*>(otile + (16 * i + r) * OP + (4 * jj + wave) * 16 + 4 * g) = acc[i][p * PT + jj];
+        __syncthreads();
+        constexpr int GPR = CP / 4;
+        for (int idx = threadIdx.x; idx < RT * GPR; idx += 256) {
+            const int row = idx / GPR, c4 = idx - row * GPR;
+            const int tp = row_tp[row];
+            if (tp < 0) continue;
+            const long u = row_u[row];
+            const float4 a4 = *reinterpret_cast<const float4*>(otile + row * OP + 4 * c4);
+            float v[4] = {a4.x, a4.y, a4.z, a4.w};
+            conv_epi_apply<T>(e, u, tp, nb + p * CP + 4 * c4, v);
+        }
     }
 }
 
@@ -155,21 +164,30 @@ void launch_halo(hipStream_t st, const T* W, const T* X, int K, int C, int taps,
 
 template <typename T>
 bool try_halo(hipStream_t st, const T* W, const T* X, int K, int C, int taps, int dil, const ConvEpi& e) {
-    // 64-row x 128-column tiles when N allows (a block then owns whole 256-byte runs of every output row), else
-    // 128-row x 64-column tiles once there are enough of them; wider per-wave tiles would push the accumulators past
-    // what the compiler keeps in registers.
+    // Tile shapes (rows x columns per block): 64 x 256 when N allows (four MFMAs per LDS fragment), 128 x 128 for
+    // 128-column layers with many rows (halves the weight traffic), 64 x 128, else 128 x 64 / 64 x 64.
     const size_t row_bytes = (size_t)C * sizeof(T);
     const size_t halo = (size_t)(taps - 1) * dil;
     constexpr size_t LDS_MAX = 64 * 1024;
-    const bool wide = e.N % 128 == 0;
-    const bool tall = !wide && e.M >= 128L * 512 && (128 + halo) * row_bytes <= LDS_MAX;
-    const int rows = tall ? 128 : 64, cols = wide ? 128 : 64;
-    const size_t lds = std::max((rows + halo) * row_bytes, (size_t)rows * (cols + 4) * 4);
-    if (lds > LDS_MAX) return false;
-    const long gy = (e.M + rows - 1) / rows;
-    if (gy > 0x7fffffffL) return false;
-    if (wide) launch_halo<T, 4, 2>(st, W, X, K, C, taps, dil, e, lds);
-    else if (tall) launch_halo<T, 8, 1>(st, W, X, K, C, taps, dil, e, lds);
+    const size_t otile64 = (size_t)64 * 132 * 4, otile128 = (size_t)128 * 68 * 4;
+    const bool fits128 = std::max((128 + halo) * row_bytes, otile128) <= LDS_MAX;
+    const bool fits64 = std::max((64 + halo) * row_bytes, otile64) <= LDS_MAX;
+    const bool many = e.M >= 128L * 512;
+    static const int tune = getenv("QTTS_CONV_TILE") ? atoi(getenv("QTTS_CONV_TILE")) : 0;  // bit 0: 64x256 tiles, bit 1: 128x128 tiles
+    int mt, nt;
+    if ((tune & 1) && e.N % 256 == 0 && fits64) { mt = 4; nt = 4; }
+    else if ((tune & 2) && e.N % 128 == 0 && many && fits128) { mt = 8; nt = 2; }
+    else if (e.N % 128 == 0 && fits64) { mt = 4; nt = 2; }
+    else if (many && fits128) { mt = 8; nt = 1; }
+    else if (fits64) { mt = 4; nt = 1; }
+    else return false;
+    const int rows = 16 * mt;
+    const size_t lds = std::max((rows + halo) * row_bytes, mt == 8 ? otile128 : otile64);
+    if ((e.M + rows - 1) / rows > 0x7fffffffL) return false;
+    if (mt == 4 && nt == 4) launch_halo<T, 4, 4>(st, W, X, K, C, taps, dil, e, lds);
+    else if (mt == 8 && nt == 2) launch_halo<T, 8, 2>(st, W, X, K, C, taps, dil, e, lds);
+    else if (mt == 4 && nt == 2) launch_halo<T, 4, 2>(st, W, X, K, C, taps, dil, e, lds);
+    else if (mt == 8) launch_halo<T, 8, 1>(st, W, X, K, C, taps, dil, e, lds);
     else launch_halo<T, 4, 1>(st, W, X, K, C, taps, dil, e, lds);
     return true;
 }
