@@ -1,0 +1,94 @@
+"""The benchmark configurations that are not the headline run, at their real shapes and batch sizes with shortened
+generation lengths.  The CPU oracle cannot reach these sizes in seconds, so each case checks properties of the algorithm:
+determinism, batch-composition independence, length arithmetic, value ranges."""
+import numpy as np
+import pytest
+
+from conftest import SEED
+from golden.make_golden import GREEDY, test_audio as make_audio
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(shape, model_type, talker=True, codec=False, speaker=False, dtype="bf16"):
+    import torch
+    from qwen3_tts_rs_amd import LoaderConfig, Model, synth
+    cfg, ccfg, tmpl = synth.shape_set(shape, model_type)
+    m = Model(cfg, ccfg if codec else None, LoaderConfig(dtype=dtype))
+    keys = (synth.talker_keys(cfg) if talker else []) + (synth.speaker_keys(cfg) if speaker else []) + (synth.codec_keys(ccfg) if codec else [])
+    for k, t in synth.iter_weights_torch(keys, SEED, "cuda:0", dtype == "bf16"):
+        m.load_tensor(k, t)
+    m.finalize()
+    torch.cuda.empty_cache()
+    return m, cfg, ccfg, tmpl
+
+
+def _greedy():
+    from qwen3_tts_rs_amd import SamplingConfig
+    return SamplingConfig(**{k: GREEDY[k] for k in SamplingConfig().__dict__})
+
+
+def test_small_model_batch_one_decode_and_codec():
+    """0.6B-like Base model, batch 1: decode + codec decode end to end."""
+    from qwen3_tts_rs_amd import GenerationRequest, synth
+    m, cfg, ccfg, tmpl = _model("S06", "base", codec=True)
+    try:
+        text = synth.synthetic_text_ids(tmpl, 12, 1)
+        xvec = synth.make_tensor("cfg2.xvector", (cfg["talker_config"]["hidden_size"],), "normal:1.0", SEED)
+        req = GenerationRequest(text_ids=text, language="english", speaker_embed=xvec)
+        a = m.generate([req], _greedy(), 40)
+        b = m.generate([req], _greedy(), 40, use_graph=False)
+        assert np.array_equal(a.codes, b.codes) and a.num_steps == 40
+        wav = m.decode_output(a)[0]
+        assert len(wav) == 1920 * a.effective_lengths[0] - 555 and np.isfinite(wav).all() and np.abs(wav).max() <= 1.0
+        # the same utterance inside a batch of other utterances produces the same codes up to bf16 near-ties of the
+        # batched GEMM path: the first frame's first codebook is decided by the prefill alone and must agree
+        others = [GenerationRequest(text_ids=synth.synthetic_text_ids(tmpl, 9 + i, 10 + i), language="english", speaker_embed=xvec) for i in range(3)]
+        c = m.generate([req] + others, _greedy(), 4)
+        assert c.codes[0, 0, 0] == a.codes[0, 0, 0]
+    finally:
+        m.close()
+
+
+def test_voice_clone_batch_256():
+    """1.7B-like Base model, 256 reference clips: mel + ECAPA on the device, x-vector prompts, batched decode."""
+    from qwen3_tts_rs_amd import GenerationRequest, synth
+    m, cfg, ccfg, tmpl = _model("S17", "base", speaker=True)
+    try:
+        n = 256
+        clips = [make_audio(72000 + 641 * (i % 257), i % 11) for i in range(n)]     # 3.0 - 9.9 s at 24 kHz
+        emb = m.extract_speaker_embedding(clips)
+        assert emb.shape == (n, cfg["talker_config"]["hidden_size"]) and np.isfinite(emb).all()
+        again = m.extract_speaker_embedding(clips[:7])
+        assert np.abs(again - emb[:7]).max() <= 2e-2 * np.abs(emb[:7]).max()
+        reqs = [GenerationRequest(text_ids=synth.synthetic_text_ids(tmpl, 8 + i % 40, i), language="english", speaker_embed=emb[i])
+                for i in range(n)]
+        out = m.generate(reqs, _greedy(), 3)
+        assert out.codes.shape == (n, 3, cfg["talker_config"]["num_code_groups"])
+        t = cfg["talker_config"]
+        assert (out.codes[:, :, 0] < t["vocab_size"]).all() and (out.codes[:, :, 1:] < t["code_predictor_config"]["vocab_size"]).all()
+        sub = m.generate(reqs[64:128], _greedy(), 3)     # rows do not depend on their batch
+        assert (sub.codes[:, 0, 0] == out.codes[64:128, 0, 0]).mean() > 0.9
+    finally:
+        m.close()
+
+
+def test_long_form_codec_decode():
+    """Codec standalone, 10-minute sequences (7500 frames): decode_output's policy chunks them (256 / 32)."""
+    m, cfg, ccfg, tmpl = _model("S17", "custom_voice", talker=False, codec=True)
+    try:
+        rng = np.random.default_rng(3)
+        codes = rng.integers(0, 2048, (3, 7500, 16)).astype(np.uint32)
+        wavs = m.decode_codes(codes, [7500, 6000, 513], chunk=-2)
+        for w, T in zip(wavs, (7500, 6000, 513)):
+            nchunks = -(-T // 256)
+            assert len(w) == 1920 * T - 555 * nchunks
+            assert np.isfinite(w).all() and np.abs(w).max() <= 1.0
+        # chunk i depends only on its own frames and 32 frames of left context
+        part = m.decode_codes(codes[:1, 224:512], chunk=0)[0]          # second window of row 0 with its context
+        ref = wavs[0][1920 * 256 - 555:][:1920 * 256 - 555]
+        n = min(len(ref), len(part) - 32 * 1920)
+        from conftest import snr_db
+        assert snr_db(part[32 * 1920:32 * 1920 + n], ref[:n]) > 28.0
+    finally:
+        m.close()
