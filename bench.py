@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch the decode frame kernel by kernel (counter collection cannot follow hipGraphs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=96)
+    ap.add_argument("--first-frames", type=int, default=25,
+                    help="frames of the first audio chunk (2 s): decoded as soon as they exist, while generation continues")
     return ap.parse_args()
 
 
@@ -148,13 +150,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    stats = dict(prefill_ms=0.0, frames_ms=0.0, frames=0, codec_ms=0.0, audio_s=0.0, step_ms=[])
+    stats = dict(prefill_ms=0.0, frames_ms=0.0, frames=0, codec_ms=0.0, audio_s=0.0, step_ms=[], first_ms=[])
     out_last = [None]
     lock = threading.Lock()
 
     def step(mod, record):
         t_s = time.perf_counter()
-        out = mod.generate(reqs, sampling, args.frames, use_graph=not args.no_graph)
+        first_ms = []
+
+        def on_first(codes):
+            # the codec decoder is causal: all but the last two frames of this prefix decode to final audio
+            mod.decode_codes(codes)
+            first_ms.append((time.perf_counter() - t_s) * 1e3)
+
+        stream_first = not args.no_codec and 2 < args.first_frames < args.frames
+        out = mod.generate(reqs, sampling, args.frames, use_graph=not args.no_graph, first_frames=args.first_frames if stream_first else 0,
+                           on_first_chunk=on_first if stream_first else None)
         wavs = [] if args.no_codec else mod.decode_output(out)
         if record:
             with lock:
@@ -164,6 +175,7 @@ def main():
                 stats["codec_ms"] += 0.0 if args.no_codec else mod.codec_device_ms()
                 stats["audio_s"] += sum(out.effective_lengths) * FRAME_SECONDS
                 stats["step_ms"].append((time.perf_counter() - t_s) * 1e3)
+                stats["first_ms"].append(first_ms[0] if first_ms else stats["step_ms"][-1])
                 out_last[0] = out
         return out, wavs
 
@@ -252,8 +264,10 @@ def main():
                                    f"{args.frames} frames each ({'greedy' if args.greedy else 'seeded sampling'}), codec decode "
                                    f"{'off' if args.no_codec else 'to 24 kHz waveforms on the host'}",
                        "batch_per_gpu": args.batch, "frames": args.frames, "parallelism": f"dp{world} (per-utterance)"},
-            # non-streaming path: audio exists once the utterance's whole step (generate + decode) is done
-            "p50_first_audio_ms": round(float(np.median(stats["step_ms"])), 1), "batches_in_flight": P,
+            # first audio = the first `first_frames` frames (final samples for all but the last two frames) decoded and on the
+            # host while generation continues; full utterance = the reference's own (non-streaming) definition
+            "p50_first_audio_ms": round(float(np.median(stats["first_ms"])), 1), "first_audio_frames": args.first_frames,
+            "p50_full_utterance_ms": round(float(np.median(stats["step_ms"])), 1), "batches_in_flight": P,
             "phase_ms_per_step": {"prefill": round(stats["prefill_ms"] / args.steps, 2), "frames": round(stats["frames_ms"] / args.steps, 2),
                                   "codec_device": round(stats["codec_ms"] / args.steps, 2)},
             "ms_per_frame": round(ms_per_frame, 4),

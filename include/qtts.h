@@ -106,6 +106,14 @@ typedef struct {
     float* hidden;
     int use_graph;     /* 1: replay the decode frame as a hipGraph (default path), 0: eager launches */
     int profile_gemm;  /* eager only: time every weight-streaming GEMM launch with HIP events */
+    /* First-audio hook (no counterpart in the reference, whose generate returns only when every frame exists): once
+     * `first_frames` frames of every row exist, chunk_cb(chunk_user, codes [n][first_frames][groups], n, first_frames) is
+     * called on the calling thread (at the end of generation with fewer frames if it stops earlier).  The codec decoder
+     * is causal, so decoding that prefix gives final audio for all but its last two frames; the callback may call
+     * qtts_codec_decode on the same model. */
+    int first_frames;
+    void (*chunk_cb)(void* user, const uint32_t* codes, int n, int frames);
+    void* chunk_user;
 } qtts_gen_debug;
 
 /* ConditionalGeneration::generate (nn/generation.rs:815-1194) for n independent utterances decoded as

@@ -591,8 +591,20 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         QTTS_HIP(hipGraphInstantiate(&g.graph_exec, graph, nullptr, nullptr, 0));
         QTTS_HIP(hipGraphDestroy(graph));
     }
+    // first-audio hook: hand the first frames of every row to the caller as soon as they exist
+    bool chunk_sent = !(dbg && dbg->chunk_cb && dbg->first_frames > 0);
+    auto send_chunk = [&](int frames) {
+        chunk_sent = true;
+        if (frames <= 0) return;
+        std::vector<uint32_t> hc((size_t)B * frames * G);
+        QTTS_HIP(hipMemcpy2DAsync(hc.data(), (size_t)frames * G * 4, g.codes.p, (size_t)max_new * G * 4, (size_t)frames * G * 4, B,
+                                  hipMemcpyDeviceToHost, st));
+        QTTS_HIP(hipStreamSynchronize(st));
+        dbg->chunk_cb(dbg->chunk_user, hc.data(), B, frames);
+    };
     bool done = false;
     while (steps_done < max_new && !done) {
+        if (!chunk_sent && steps_done >= dbg->first_frames) send_chunk(dbg->first_frames);
         if (steps_done % EOS_POLL == 0 && all_eos()) { done = true; break; }
         if (g.graph_exec && use_graph && !tracing) {
             QTTS_HIP(hipGraphLaunch(g.graph_exec, st));
@@ -604,6 +616,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         ++steps_done;
     }
     QTTS_HIP(hipEventRecord(ev2, st));
+    if (!chunk_sent) send_chunk(std::min(steps_done, dbg->first_frames));
     all_eos();
     QTTS_HIP(hipGetLastError());
 

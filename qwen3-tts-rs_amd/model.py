@@ -243,8 +243,11 @@ class Model:
 
     # ------------------------------------------------------------------ generation
     def generate(self, requests: Sequence[GenerationRequest], sampling: SamplingConfig, max_new_tokens: int,
-                 trace: bool = False, use_graph: bool = True, profile_gemm: bool = False) -> Output:
-        """ConditionalGeneration::generate (nn/generation.rs:815) over a batch of independent utterances."""
+                 trace: bool = False, use_graph: bool = True, profile_gemm: bool = False, first_frames: int = 0,
+                 on_first_chunk=None) -> Output:
+        """ConditionalGeneration::generate (nn/generation.rs:815) over a batch of independent utterances.
+        on_first_chunk(codes (batch, first_frames, groups)) is called once the first `first_frames` frames of every row
+        exist, while generation continues afterwards (first-audio hook; the reference has no counterpart)."""
         n = len(requests)
         G = self.num_code_groups
         V = self.config["talker_config"]["vocab_size"]
@@ -296,7 +299,20 @@ class Model:
             dbg.hidden = hidden.ctypes.data_as(C.POINTER(C.c_float))
         dbg.use_graph = int(use_graph)
         dbg.profile_gemm = int(profile_gemm)
+        cb_err = []
+        if on_first_chunk is not None and first_frames > 0:
+            def _cb(_user, ptr, nrows, frames):
+                try:  # exceptions must not unwind through the C frames
+                    on_first_chunk(np.ctypeslib.as_array(ptr, shape=(nrows, frames, G)).copy())
+                except Exception as ex:
+                    cb_err.append(ex)
+            cb = _lib.CHUNK_CB(_cb)
+            keep.append(cb)
+            dbg.first_frames = int(first_frames)
+            dbg.chunk_cb = cb
         check(self.lib.qtts_generate_ex(self._m, reqs, n, C.byref(sc), max_new_tokens, outs, C.byref(dbg)))
+        if cb_err:
+            raise cb_err[0]
         tm = (C.c_double * 8)()
         check(self.lib.qtts_last_timing(self._m, tm, 8))
         self.last_timing = dict(prefill_ms=tm[0], frames_ms=tm[1], gemm_ms=tm[2], gemm_launches=int(tm[3]),

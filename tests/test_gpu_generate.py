@@ -117,6 +117,36 @@ def test_icl_prompt_matches_golden(t0_f32, bind, golden, non_streaming):
     assert np.array_equal(out2.codes[0], r2["codes"])
 
 
+def test_first_audio_chunk_is_a_final_prefix(golden):
+    """The first-audio hook hands over the first frames while generation goes on; decoding that prefix gives the same
+    samples as the full decode for all but its last two frames (the codec decoder is causal)."""
+    from conftest import snr_db
+    from qwen3_tts_rs_amd import synthetic_model
+    m, cfg, ccfg, tmpl = synthetic_model("T0", dtype="f32", codec=True)
+    try:
+        got = {}
+
+        def on_first(codes):
+            got["codes"] = codes
+            got["wav"] = m.decode_codes(codes)
+
+        reqs = [_req(golden["text_ids"]), _req(golden["text_ids"][:15].tolist() + golden["text_ids"][-5:].tolist())]
+        out = m.generate(reqs, _sampling(GREEDY), 40, first_frames=12, on_first_chunk=on_first)
+        assert np.array_equal(out.codes[0], golden["greedy_codes"][:40])
+        assert got["codes"].shape == (2, 12, 4) and np.array_equal(got["codes"], out.codes[:, :12])
+        full = m.decode_output(out)
+        up = 96
+        for b in range(2):
+            n = up * (12 - 2)
+            assert snr_db(full[b][:n], got["wav"][b][:n]) > 60.0
+        # a generation shorter than the chunk still delivers it once, at the end
+        got.clear()
+        out = m.generate(reqs[:1], _sampling(GREEDY), 5, first_frames=12, on_first_chunk=on_first)
+        assert got["codes"].shape == (1, 5, 4) and np.array_equal(got["codes"], out.codes[:, :5])
+    finally:
+        m.close()
+
+
 def test_streaming_text_mode(t0_f32, bind, golden):
     """non_streaming_mode = false: the text after the first token is fed one row per generated frame
     (nn/generation.rs:769-789,1096-1106)."""
