@@ -224,6 +224,40 @@ int qtts_bench_sync(qtts_ctx* ctx, int mode, int blocks, int threads, int iters,
         QTTS_HIP(hipMemcpy(h, state.p, sizeof(h), hipMemcpyDeviceToHost));
         *errors = (int)h[17] + (h[16] ? 1000000 : 0);
         *avg_us = (double)ms * 1e3 / (2.0 * iters);
+    } else if (mode >= 2) {
+        // mode 2/3/4: graph of `iters` dependent kernels (plain / 16-byte write-through / 8-byte write-through stores) over
+        // `threads` KiB of floats with `blocks` blocks; *errors != 0 when the final values are not `iters` (visibility failure)
+        const int n = threads * 256;
+        DevBuf a, b;
+        a.alloc((size_t)n * 4);
+        b.alloc((size_t)n * 4);
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        QTTS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+        for (int i = 0; i < iters; ++i) {
+            const float* src = (i & 1) ? b.as<float>() : a.as<float>();
+            float* dst = (i & 1) ? a.as<float>() : b.as<float>();
+            if (mode == 5 && (i & 1)) launch_chain_b(st, src, dst, n, blocks);   // mode 5: alternate two different kernels
+            else launch_chain(st, src, dst, n, blocks, mode == 5 ? 0 : mode - 2);
+        }
+        QTTS_HIP(hipStreamEndCapture(st, &graph));
+        QTTS_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        QTTS_HIP(hipGraphDestroy(graph));
+        for (int rep = 0; rep < 2; ++rep) {
+            QTTS_HIP(hipMemsetAsync(a.p, 0, (size_t)n * 4, st));
+            QTTS_HIP(hipEventRecord(e0, st));
+            QTTS_HIP(hipGraphLaunch(exec, st));
+            QTTS_HIP(hipEventRecord(e1, st));
+            QTTS_HIP(hipStreamSynchronize(st));
+        }
+        QTTS_HIP(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipGraphExecDestroy(exec);
+        std::vector<float> h((size_t)n);
+        QTTS_HIP(hipMemcpy(h.data(), (iters & 1) ? b.p : a.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        int bad = 0;
+        for (int i = 0; i < n; ++i) bad += h[(size_t)i] != (float)iters;
+        *errors = bad;
+        *avg_us = (double)ms * 1e3 / iters;
     } else {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;

@@ -47,7 +47,7 @@ struct CodecState {
     int maxpad = 0;  // leading zero rows of the strips inside the vocoder blocks
     // run-time buffers (grown on demand, kept between calls)
     Workspace ws;
-    DevBuf kv, toks, ptab, meta, codes, A, Bf, R, Rf, acc, wav;
+    DevBuf kv, toks, meta, codes, A, Bf, R, Rf, acc, wav;
 };
 
 void finalize_codec(Model& m) {
@@ -344,10 +344,6 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         s.ws.act.ensure(rp * c.inter * es);
         // pages: one private range per strip + one shared dump page for the padding rows
         const int pp = (Tm + PAGE - 1) / PAGE;
-        std::vector<int> ptab((size_t)(U + 1) * pp);
-        for (int u = 0; u < U; ++u)
-            for (int i = 0; i < pp; ++i) ptab[(size_t)u * pp + i] = u * pp + i;
-        for (int i = 0; i < pp; ++i) ptab[(size_t)U * pp + i] = U * pp;
         std::vector<Tok> toks((size_t)M);
         for (int u = 0; u < U; ++u)
             for (long r = 0; r < S[0]; ++r) {
@@ -361,13 +357,11 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
                 }
             }
         const size_t page_elems = (size_t)2 * c.kv_heads * PAGE * c.head_dim;
-        s.kv.ensure(((size_t)U * pp + 1) * page_elems * es);
-        s.ptab.ensure(ptab.size() * 4);
+        s.kv.ensure(((size_t)U + 1) * pp * page_elems * es);  // row U: dump pages for the padding rows
         s.toks.ensure(toks.size() * sizeof(Tok));
-        QTTS_HIP(hipMemcpyAsync(s.ptab.p, ptab.data(), ptab.size() * 4, hipMemcpyHostToDevice, st));
         QTTS_HIP(hipMemcpyAsync(s.toks.p, toks.data(), toks.size() * sizeof(Tok), hipMemcpyHostToDevice, st));
-        QTTS_HIP(hipStreamSynchronize(st));  // ptab / toks are locals
-        KVView kv{s.kv.p, 0, PAGE, c.kv_heads, c.head_dim, pp, s.ptab.as<int>()};
+        QTTS_HIP(hipStreamSynchronize(st));  // toks is a local
+        KVView kv{s.kv.p, 0, PAGE, c.kv_heads, c.head_dim, pp, nullptr};
         if (s.xf.max_pos < std::max(Tm, PAGE)) {
             int n = 256;
             while (n < Tm) n *= 2;

@@ -269,27 +269,15 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     // KV pools
     {
         const int max_pages = (max_ctx + PAGE_TOKENS - 1) / PAGE_TOKENS;
-        std::vector<int> table((size_t)B * max_pages, 0);
-        int next = 0;
-        for (int b = 0; b < B; ++b) {
-            const int np = (row_P[(size_t)b] + max_new + PAGE_TOKENS - 1) / PAGE_TOKENS;
-            for (int i = 0; i < np; ++i) table[(size_t)b * max_pages + i] = next++;
-        }
+        // every row owns max_pages consecutive pages: no page table, no dependent load in front of the K/V accesses
         const size_t page_elems = (size_t)2 * c.talker.nkv * PAGE_TOKENS * c.talker.d;
-        g.talker.pool.ensure((size_t)c.talker.layers * next * page_elems * es);
-        g.talker.table.ensure(table.size() * 4);
-        QTTS_HIP(hipMemcpyAsync(g.talker.table.p, table.data(), table.size() * 4, hipMemcpyHostToDevice, st));
-        g.talker.kv = KVView{g.talker.pool.p, (size_t)next * page_elems, PAGE_TOKENS, c.talker.nkv, c.talker.d, max_pages,
-                             g.talker.table.as<int>()};
+        const size_t npages = (size_t)B * max_pages;
+        g.talker.pool.ensure((size_t)c.talker.layers * npages * page_elems * es);
+        g.talker.kv = KVView{g.talker.pool.p, npages * page_elems, PAGE_TOKENS, c.talker.nkv, c.talker.d, max_pages, nullptr};
         QTTS_CHECK(G + 1 <= CP_PAGE_TOKENS, ERR_SHAPE, "generate: too many code groups for the code-predictor KV page");
-        std::vector<int> cpt((size_t)B);
-        for (int b = 0; b < B; ++b) cpt[(size_t)b] = b;
         const size_t cpage = (size_t)2 * c.cp.nkv * CP_PAGE_TOKENS * c.cp.d;
         g.cp.pool.ensure((size_t)c.cp.layers * B * cpage * es);
-        g.cp.table.ensure((size_t)B * 4);
-        QTTS_HIP(hipMemcpyAsync(g.cp.table.p, cpt.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-        g.cp.kv = KVView{g.cp.pool.p, (size_t)B * cpage, CP_PAGE_TOKENS, c.cp.nkv, c.cp.d, 1, g.cp.table.as<int>()};
-        QTTS_HIP(hipStreamSynchronize(st));  // the host vectors above go out of scope
+        g.cp.kv = KVView{g.cp.pool.p, (size_t)B * cpage, CP_PAGE_TOKENS, c.cp.nkv, c.cp.d, 1, nullptr};
     }
 
     // uniforms in the reference's draw order per utterance: frame by frame, cb0 first then codebooks 1..G-1
@@ -415,8 +403,10 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     const long row_stride = (long)max_new * G;
     int* d_step = g.step.as<int>();
 
-    auto sample = [&](const float* logits, int vocab, int gcol, bool talker) {
+    auto sample = [&](const float* logits, int vocab, int gcol, bool talker, const void* next_table = nullptr, void* next_dst = nullptr,
+                      int next_dst_dtype = F32) {
         SampleArgs a{};
+        a.next_table = next_table; a.next_dst = next_dst; a.next_H = H; a.next_table_bf16 = dt == BF16; a.next_dst_bf16 = next_dst_dtype == BF16;
         a.logits = logits; a.V = vocab; a.B = B;
         const double T = talker ? sp->temperature : sp->subtalker_temperature;
         a.temperature = T == 1.0 ? 1.0f : (float)(1.0 / T);
@@ -501,38 +491,39 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         if (eager_trace && trace_l) {
             // step index is only known on the device; trace copies use the host's mirror of it
         }
-        sample(g.ws.part.as<float>(), V, 0, true);
+        // every sampler also copies the embedding row of the code it drew to where the next pass reads its input
+        // (model dtype in front of the H -> Hc projection, f32 when the code predictor is as wide as the talker)
+        void* in0 = m.proj ? (void*)((char*)g.cp_in_t.p + (size_t)B * H * es) : (void*)(g.cp_in_f.as<float>() + (size_t)B * H);
+        void* inj = m.proj ? g.ws.act.p : g.ws.q.p;
+        const int in_dt = m.proj ? dt : F32;
+        sample(g.ws.part.as<float>(), V, 0, true, m.codec_emb, in0, in_dt);
         // ---- code predictor pass 0: [hidden, embed(cb0)] at positions 0, 1
         const Tok* ct = g.toks_cp.as<Tok>();
         if (m.proj) {
-            launch_gather_codes(st, m.codec_emb, dt, g.codes.as<unsigned>(), row_stride, d_step, G, 0, (char*)g.cp_in_t.p + (size_t)B * H * es, dt, B, H);
             const int ks = R.ks_for(2 * B, Hc, H);
             R.gemm(m.proj, g.cp_in_t.p, 2 * B, Hc, H, ks, H);
             launch_resid_norm(st, dt, nullptr, g.ws.part.as<float>(), ks, R.kstride(2 * B, Hc), m.proj_b, nullptr, m.cp.layers[0].ln1, c.cp.eps,
                               g.ws.x.as<float>(), g.ws.xn.p, nullptr, 2 * B, Hc);
         } else {
-            launch_gather_codes(st, m.codec_emb, dt, g.codes.as<unsigned>(), row_stride, d_step, G, 0, g.cp_in_f.as<float>() + (size_t)B * H, F32, B, H);
             launch_resid_norm(st, dt, nullptr, g.cp_in_f.as<float>(), 1, 0, nullptr, nullptr, m.cp.layers[0].ln1, c.cp.eps, g.ws.x.as<float>(),
                               g.ws.xn.p, nullptr, 2 * B, Hc);
         }
         R.stack(m.cp, 2 * B, ct, g.cp.kv, g.ws.xn.p, nullptr);
         R.gemm(m.cp_head[0], (char*)g.ws.xn.p + (size_t)B * Hc * es, B, Vc, Hc, 1, Hc);
-        sample(g.ws.part.as<float>(), Vc, 1, false);
+        sample(g.ws.part.as<float>(), Vc, 1, false, G > 2 ? m.cp_emb[0] : nullptr, inj, in_dt);
         for (int j = 1; j < G - 1; ++j) {  // code_predictor.rs:480-527
             if (m.proj) {
-                launch_gather_codes(st, m.cp_emb[(size_t)j - 1], dt, g.codes.as<unsigned>(), row_stride, d_step, G, j, g.ws.act.p, dt, B, H);
                 const int ks = R.ks_for(B, Hc, H);
                 R.gemm(m.proj, g.ws.act.p, B, Hc, H, ks, H);
                 launch_resid_norm(st, dt, nullptr, g.ws.part.as<float>(), ks, R.kstride(B, Hc), m.proj_b, nullptr, m.cp.layers[0].ln1, c.cp.eps,
                                   g.ws.x.as<float>(), g.ws.xn.p, nullptr, B, Hc);
             } else {
-                launch_gather_codes(st, m.cp_emb[(size_t)j - 1], dt, g.codes.as<unsigned>(), row_stride, d_step, G, j, g.ws.q.p, F32, B, H);
                 launch_resid_norm(st, dt, nullptr, g.ws.q.as<float>(), 1, 0, nullptr, nullptr, m.cp.layers[0].ln1, c.cp.eps, g.ws.x.as<float>(), g.ws.xn.p,
                                   nullptr, B, Hc);
             }
             R.stack(m.cp, B, ct + 2 * B + (size_t)j * B, g.cp.kv, g.ws.xn.p, nullptr, true, true);
             R.gemm(m.cp_head[(size_t)j], g.ws.xn.p, B, Vc, Hc, 1, Hc);
-            sample(g.ws.part.as<float>(), Vc, j + 1, false);
+            sample(g.ws.part.as<float>(), Vc, j + 1, false, j + 1 < G - 1 ? m.cp_emb[(size_t)j] : nullptr, inj, in_dt);
         }
         // ---- next talker input (talker.rs:461-479 + generation.rs:1096-1106) and its layer-0 norm
         EmbedSumArgs ea{};

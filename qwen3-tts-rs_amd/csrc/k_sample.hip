@@ -242,6 +242,28 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
             token = sh_tok;
         }
     }
+    // the sampled code's embedding row is the next code-predictor pass's input: copy it here instead of in a kernel of its own
+    if (a.next_table) {
+        const int H = a.next_H;
+        if (a.next_table_bf16) {
+            const bf16_t* src = (const bf16_t*)a.next_table + (long)token * H;
+            if (a.next_dst_bf16) {
+                bf16_t* dst = (bf16_t*)a.next_dst + (long)b * H;
+                for (int i = tid * 8; i < H; i += 256 * 8) *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(src + i);
+            } else {
+                float* dst = (float*)a.next_dst + (long)b * H;
+                for (int i = tid * 8; i < H; i += 256 * 8) {
+                    float v[8];
+                    load8(src + i, v);
+                    store8(dst + i, v);
+                }
+            }
+        } else {
+            const float* src = (const float*)a.next_table + (long)token * H;
+            float* dst = (float*)a.next_dst + (long)b * H;
+            for (int i = tid * 4; i < H; i += 256 * 4) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
+        }
+    }
     if (tid == 0) {
         a.codes_base[(long)b * a.row_stride + (long)step * a.G + a.g] = (unsigned)token;
         if (a.g == 0) {
@@ -255,6 +277,8 @@ void launch_sample(hipStream_t st, const SampleArgs& a) {
     QTTS_CHECK(a.V >= 1 && a.V <= SAMPLE_MAX_V, ERR_SHAPE, "sample: vocabulary larger than the LDS staging buffer");
     QTTS_CHECK(a.B >= 1 && a.G >= 1 && a.g >= 0 && a.g < a.G && a.row_stride % a.G == 0, ERR_SHAPE, "sample: bad shape");
     QTTS_CHECK(!a.do_sample || a.uniforms != nullptr, ERR_BAD_ARG, "sample: uniforms required when sampling");
+    QTTS_CHECK(a.next_table == nullptr || (a.next_dst != nullptr && a.next_H % 8 == 0 && (a.next_table_bf16 || !a.next_dst_bf16)), ERR_BAD_ARG,
+               "sample: bad next-row description");
     hipLaunchKernelGGL(sample_kernel, dim3(a.B), dim3(256), 0, st, a);
 }
 

@@ -17,7 +17,7 @@ struct KVView {
     void* base;
     size_t layer_stride;  // elements
     int page_tokens, nkv, d, max_pages;
-    const int* page_table;
+    const int* page_table;  // null: row r owns pages [r * max_pages, (r + 1) * max_pages)
 };
 
 // ---- k_gemm.hip
@@ -62,6 +62,8 @@ void launch_stream(hipStream_t st, const void* src, unsigned* sink, long bytes, 
 
 void launch_barrier_bench(hipStream_t st, unsigned* state, int blocks, int threads, int iters);
 void launch_null(hipStream_t st);
+void launch_chain(hipStream_t st, const float* in, float* out, int n, int blocks, int mode);
+void launch_chain_b(hipStream_t st, const float* in, float* out, int n, int blocks);
 
 // ---- k_elem.hip
 // x = [resid] + [scale *] (sum_ks part[ks] + [bias]); resid_out = x (f32, may alias resid); xn = rmsnorm(x) * w -> dtype;
@@ -158,6 +160,10 @@ struct SampleArgs {
     long row_stride;
     int G, g;               // which codebook column this draw fills
     int* eos_step;          // [B], -1 until the row's first EOS (only for g == 0)
+    // optional: copy next_table[token] (H elements, bf16 or f32) to next_dst row b (same dtype, or f32 from a bf16 table)
+    const void* next_table;
+    void* next_dst;
+    int next_H, next_table_bf16, next_dst_bf16;
 };
 void launch_sample(hipStream_t st, const SampleArgs& a);
 
