@@ -1,0 +1,138 @@
+"""GPU parity on the configuration corners of the generate path: long prompts (chunked prefill), sliding-window talker
+attention, attention biases, top-p sampling, disabled repetition penalty, mixed greedy / sampled stages, single-frame
+runs.  fp32, token-exact against the CPU oracle."""
+import copy
+
+import numpy as np
+import pytest
+
+from conftest import SEED, make_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(bind, mutate=None, shape="T0"):
+    """(GPU model, oracle, cfg, template) for a shape set whose talker config was edited by `mutate`."""
+    from qwen3_tts_rs_amd import LoaderConfig, Model, synth
+    cfg, ccfg, tmpl = synth.shape_set(shape)
+    cfg = copy.deepcopy(cfg)
+    if mutate:
+        mutate(cfg)
+    keys = synth.talker_keys(cfg)
+    m = Model(cfg, None, LoaderConfig(dtype="f32"))
+    o = bind.Oracle()
+    for k, a in synth.iter_weights(keys, SEED):
+        m.load_tensor(k, a)
+        o.load_tensor(k, a)
+    m.finalize()
+    o.set_model_config(cfg)
+    return m, o, cfg, tmpl
+
+
+def _check(bind, m, o, cfg, texts, sampling, steps, seeds=None, **okw):
+    from qwen3_tts_rs_amd import GenerationRequest, SamplingConfig
+    sc = SamplingConfig(**{k: sampling[k] for k in SamplingConfig().__dict__})
+    reqs = [GenerationRequest(text_ids=t, language="english", speaker="speaker1", seed=None if seeds is None else seeds[i])
+            for i, t in enumerate(texts)]
+    out = m.generate(reqs, sc, steps)
+    for i, t in enumerate(texts):
+        r = o.generate(t, bind.resolve_codec_prefill(cfg, "english", "speaker1"), sampling, steps, seed=0 if seeds is None else seeds[i],
+                       speaker_token=bind.resolve_speaker_token(cfg, "speaker1"), **okw)
+        assert np.array_equal(r["codes"], out.codes[i][:r["num_steps"]]), f"utterance {i}"
+    return out
+
+
+BASE = dict(do_sample=False, subtalker_do_sample=False, temperature=1.0, top_k=50, top_p=1.0, repetition_penalty=1.05,
+            subtalker_temperature=0.9, subtalker_top_k=50, subtalker_top_p=1.0)
+
+
+def test_long_prompt_spans_several_prefill_chunks(bind):
+    from qwen3_tts_rs_amd import synth
+    m, o, cfg, tmpl = _pair(bind)
+    try:
+        texts = [synth.synthetic_text_ids(tmpl, n, i) for i, n in enumerate([1300, 40, 700])]   # 2000+ prompt positions in one batch
+        _check(bind, m, o, cfg, texts, BASE, 6)
+    finally:
+        m.close()
+
+
+def test_sliding_window_talker(bind):
+    """A non-null `sliding_window` in the talker config limits every query to its last W keys (talker_config.rs:360-362)."""
+    from qwen3_tts_rs_amd import synth
+
+    def mut(cfg):
+        cfg["talker_config"]["sliding_window"] = 16
+
+    m, o, cfg, tmpl = _pair(bind, mut)
+    try:
+        texts = [synth.synthetic_text_ids(tmpl, n, i) for i, n in enumerate([30, 12])]
+        out = _check(bind, m, o, cfg, texts, BASE, 24)
+        m2, o2, cfg2, _ = _pair(bind)
+        try:
+            ref = _check(bind, m2, o2, cfg2, texts, BASE, 24)
+            assert not np.array_equal(ref.codes, out.codes)       # the window really changes the result
+        finally:
+            m2.close()
+    finally:
+        m.close()
+
+
+def test_attention_bias(bind):
+    from qwen3_tts_rs_amd import synth
+
+    def mut(cfg):
+        cfg["talker_config"]["attention_bias"] = True
+        cfg["talker_config"]["code_predictor_config"]["attention_bias"] = True
+
+    m, o, cfg, tmpl = _pair(bind, mut)
+    try:
+        _check(bind, m, o, cfg, [synth.synthetic_text_ids(tmpl, 14, 2)], BASE, 10)
+    finally:
+        m.close()
+
+
+@pytest.mark.parametrize("name,delta", [
+    ("top_p", dict(do_sample=True, subtalker_do_sample=True, top_p=0.8, subtalker_top_p=0.7, temperature=0.9)),
+    ("no_top_k", dict(do_sample=True, subtalker_do_sample=True, top_k=0, subtalker_top_k=0)),
+    ("no_penalty_hot", dict(do_sample=True, subtalker_do_sample=True, repetition_penalty=1.0, temperature=1.3, subtalker_temperature=1.0)),
+    ("mixed_greedy_talker", dict(do_sample=False, subtalker_do_sample=True)),
+    ("mixed_greedy_subtalker", dict(do_sample=True, subtalker_do_sample=False)),
+    ("strong_penalty", dict(repetition_penalty=1.8)),
+])
+def test_sampling_variants(bind, name, delta):
+    from qwen3_tts_rs_amd import synth
+    m, o, cfg, tmpl = _pair(bind)
+    try:
+        texts = [synth.synthetic_text_ids(tmpl, 10 + 3 * i, i) for i in range(3)]
+        _check(bind, m, o, cfg, texts, dict(BASE, **delta), 32, seeds=[42, 7, 2026])
+    finally:
+        m.close()
+
+
+def test_single_frame_and_minimal_text(bind):
+    from qwen3_tts_rs_amd import synth
+    m, o, cfg, tmpl = _pair(bind)
+    try:
+        texts = [synth.synthetic_text_ids(tmpl, 1, 0), synth.synthetic_text_ids(tmpl, 12, 1)]
+        _check(bind, m, o, cfg, texts, BASE, 1)
+        _check(bind, m, o, cfg, texts, BASE, 2)
+        # nine ids is the shortest prompt of the non-streaming branch; eight takes the streaming layout (nn/generation.rs:699)
+        _check(bind, m, o, cfg, [texts[0][[0, 1, 2, 3, -5, -4, -3, -2, -1]][:8]], BASE, 3)
+    finally:
+        m.close()
+
+
+def test_mid_size_codec_f32(bind):
+    """Mid-size talker shapes share the tiny codec; its f32 decode of generated codes stays above the waveform bar."""
+    from conftest import snr_db
+    from qwen3_tts_rs_amd import synthetic_model
+    m, cfg, ccfg, tmpl = synthetic_model("M0", dtype="f32", codec=True, talker=False)
+    o, _, _, _ = make_oracle(bind, "M0", "f32", talker=False, codec=True)
+    try:
+        codes = np.random.default_rng(9).integers(0, 256, (2, 50, 4)).astype(np.uint32)
+        wavs = m.decode_codes(codes, [50, 17])
+        for b, L in enumerate([50, 17]):
+            ref = o.codec_decode(codes[b, :L])
+            assert len(ref) == len(wavs[b]) and snr_db(ref, wavs[b]) >= 40.0
+    finally:
+        m.close()
