@@ -149,6 +149,12 @@ int qtts_bench_stream(qtts_ctx* ctx, long bytes, int blocks, int pattern, int un
 int qtts_codec_decode(qtts_model* m, const uint32_t* codes, const int* lens, int B, int T_max, int chunk, int left_ctx,
                       float* wav_out, int64_t wav_stride, int64_t* wav_lens);
 
+/* TokenizerV2::encode / Model::encode_audio (audio/tokenizer/v2/mod.rs:164-171, audio/encoder/v2.rs:87-120): 24 kHz clips
+ * audio [B][max_samples] -> codes_out [B][T_cap][num_quantizers], T_out[b] = n_samples[b] / 1920 frames.  Needs the speech
+ * tokenizer's `encoder.*` tensors (acoustic codebooks beyond num_quantizers - 1 may be omitted). */
+int qtts_encode_audio(qtts_model* m, const float* audio, const int* n_samples, int B, int max_samples, int num_quantizers,
+                      uint32_t* codes_out, int T_cap, int* T_out);
+
 /* mel_spectrogram (audio/mel.rs:81-158, default config) as used by Model::compute_mel_spectrogram
  * (model/mod.rs:520-528): audio [B][max_samples] f32 @ 24 kHz -> mel_out [B][frames_stride][128]. */
 int qtts_mel(qtts_model* m, const float* audio, const int* n_samples, int B, int max_samples, float* mel_out,

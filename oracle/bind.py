@@ -207,6 +207,14 @@ class Oracle:
         self._chk(self.lib.orc_codec_trace(self.h, _vp(c), T, stage, _vp(out), C.c_int64(cap), C.byref(n)))
         return out[:n.value].copy()
 
+    def encode_audio(self, audio: np.ndarray, valid_q: int = 16):
+        a = np.ascontiguousarray(audio, np.float32)
+        cap = (len(a) // 1920 + 2) * valid_q
+        codes = np.zeros(cap, np.uint32)
+        T = C.c_int(0)
+        self._chk(self.lib.orc_encode_audio(self.h, _vp(a), len(a), valid_q, _vp(codes), C.c_int64(cap), C.byref(T)))
+        return codes[:T.value * valid_q].reshape(T.value, valid_q).copy()
+
     def speaker_embed(self, mel: np.ndarray):
         m = np.ascontiguousarray(mel, np.float32)
         out = np.zeros(self.cfg["speaker_encoder_config"]["enc_dim"], np.float32)

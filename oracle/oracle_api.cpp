@@ -13,6 +13,7 @@ struct Handle {
     Model model;
     CodecModel codec;
     SpeakerModel spk;
+    Weights enc;  // codec encoder tensors ("encoder.*")
     std::string err;
 };
 thread_local std::string g_err;
@@ -50,6 +51,7 @@ int orc_load_tensor(void* hv, const char* key, const float* data, const int64_t*
     t.v.assign(data, data + n);
     std::string k(key);
     if (k.rfind("decoder.", 0) == 0) h->codec.w[k] = std::move(t);
+    else if (k.rfind("encoder.", 0) == 0) h->enc[k] = std::move(t);
     else if (k.rfind("speaker_encoder.", 0) == 0) h->spk.w[k] = std::move(t);
     else h->model.w[k] = std::move(t);
     ORC_CATCH
@@ -233,6 +235,17 @@ int orc_codec_trace(void* hv, const uint32_t* codes, int T, int stage, float* ou
     if ((int64_t)src->size() > cap) throw std::runtime_error("oracle: trace buffer too small");
     std::memcpy(out, src->data(), src->size() * sizeof(float));
     *n_out = (int64_t)src->size();
+    ORC_CATCH
+}
+
+int orc_encode_audio(void* hv, const float* audio, int n, int valid_q, uint32_t* codes, int64_t cap, int* T_out) {
+    ORC_TRY
+    std::vector<uint32_t> c;
+    int T = 0;
+    encode_audio(((Handle*)hv)->enc, audio, n, valid_q, c, T);
+    if ((int64_t)c.size() > cap) throw std::runtime_error("oracle: code buffer too small");
+    std::memcpy(codes, c.data(), c.size() * sizeof(uint32_t));
+    *T_out = T;
     ORC_CATCH
 }
 

@@ -50,6 +50,9 @@ struct SpeakerModel {
     void forward(const float* mel, int T, float* out) const;
 };
 
+// TokenizerV2Encoder::encode (audio/encoder/v2.rs:87-120): 24 kHz waveform -> codes [T][valid_q]; weights under "encoder."
+void encode_audio(const Weights& w, const float* audio, int n, int valid_q, std::vector<uint32_t>& codes, int& T_out);
+
 // audio/mel.rs:81-158 with the default MelSpectrogramConfig; returns [frames][128] (the layout
 // Model::compute_mel_spectrogram hands to the speaker encoder).  n_frames is set.
 void mel_spectrogram(const float* audio, int n, std::vector<float>& mel, int& n_frames);

@@ -145,6 +145,14 @@ int qtts_codec_decode(qtts_model* m, const uint32_t* codes, const int* lens, int
     QTTS_API_END
 }
 
+int qtts_encode_audio(qtts_model* m, const float* audio, const int* n_samples, int B, int max_samples, int num_quantizers,
+                      uint32_t* codes_out, int T_cap, int* T_out) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(m && audio && n_samples && codes_out && T_out, ERR_BAD_ARG, "qtts_encode_audio: null argument");
+    run_encode_audio(m->m, audio, n_samples, B, max_samples, num_quantizers, codes_out, T_cap, T_out);
+    QTTS_API_END
+}
+
 int qtts_mel(qtts_model* m, const float* audio, const int* n_samples, int B, int max_samples, float* mel_out, int frames_stride,
              int* n_frames) {
     QTTS_API_BEGIN

@@ -62,8 +62,11 @@ __device__ __forceinline__ void conv_epi_apply(const ConvEpi& e, long u, int tp,
     } else if (e.act >= 2) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            v[q] = fmaxf(v[q], 0.f);
-            if (e.act == 3) v[q] = tanhf(v[q]);
+            if (e.act == 4) v[q] = v[q] > 0.f ? v[q] : expf(v[q]) - 1.0f;  // ELU(alpha = 1)
+            else {
+                v[q] = fmaxf(v[q], 0.f);
+                if (e.act == 3) v[q] = tanhf(v[q]);
+            }
         }
     }
     if (e.scale) {
@@ -90,7 +93,14 @@ __device__ __forceinline__ void conv_epi_apply(const ConvEpi& e, long u, int tp,
         for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(v[q]);
     }
     if (e.out_f32) *reinterpret_cast<float4*>(e.out_f32 + o_off) = make_float4(v[0], v[1], v[2], v[3]);
-    if (e.out2) {
+    if (e.out2 && e.act2 == 1) {  // ELU of the value the next op would read
+        T* o = (T*)e.out2 + o_off;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float x = e.out_f32 ? v[q] : to_f32<T>(from_f32<T>(v[q]));
+            o[q] = from_f32<T>(x > 0.f ? x : expf(x) - 1.0f);
+        }
+    } else if (e.out2) {
         float al[4], den[4];
         ld4(e.alpha_exp + co, al);
         ld4(e.beta_den + co, den);

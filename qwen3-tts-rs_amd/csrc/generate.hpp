@@ -12,6 +12,10 @@ void finalize_codec(Model& m);
 void run_codec_decode(Model& m, const uint32_t* codes, const int* lens, int B, int T_max, int chunk, int left_ctx, float* wav_out,
                       int64_t wav_stride, int64_t* wav_lens);
 
+void finalize_encoder(Model& m);
+void run_encode_audio(Model& m, const float* audio, const int* n_samples, int B, int max_samples, int Q, uint32_t* codes_out, int T_cap,
+                      int* T_out);
+
 void finalize_speaker(Model& m);
 void run_mel(Model& m, const float* audio, const int* n_samples, int B, int max_samples, float* mel_out, int frames_stride,
              int* n_frames);

@@ -146,6 +146,7 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const float* __restrict__
         for (int k = 1; k < KS; ++k) s += part[k * ks_stride + e];
         if (bias) s += bias[e % N];
         if (act == 1) s = s / (1.0f + expf(-s));
+        else if (act == 2) s = 0.5f * s * (1.0f + erff(s * 0.70710678118654752440f));  // exact GELU (Tensor::gelu_erf)
         out[e] = from_f32<T>(s);
     }
 }

@@ -359,7 +359,7 @@ void launch_gemm_rows_epi(hipStream_t st, int dtype, const void* W, const void* 
     QTTS_CHECK(M >= 1 && N % 64 == 0 && taps >= 1 && K % taps == 0, ERR_SHAPE, "gemm_rows: N must be a multiple of 64");
     QTTS_CHECK(e.N % 4 == 0 && e.Cout % 4 == 0 && e.N == e.r * e.Cout && e.Cvalid % 4 == 0 && e.lens && e.S_in >= 1, ERR_SHAPE,
                "gemm_rows: bad epilogue shape");
-    QTTS_CHECK(e.out2 == nullptr || (e.alpha_exp && e.beta_den), ERR_BAD_ARG, "gemm_rows: snake output without parameters");
+    QTTS_CHECK(e.out2 == nullptr || e.act2 == 1 || (e.alpha_exp && e.beta_den), ERR_BAD_ARG, "gemm_rows: snake output without parameters");
     const int chunk = dtype == BF16 ? 64 : 32;
     QTTS_CHECK((K / taps) % chunk == 0, ERR_SHAPE, "gemm_rows: channels per tap must be a multiple of the K chunk");
     static const bool halo_off = getenv("QTTS_CONV_HALO") && atoi(getenv("QTTS_CONV_HALO")) == 0;

@@ -74,7 +74,7 @@ void launch_resid_norm(hipStream_t st, int dtype, const float* resid, const floa
                        float* xn_f32, int M, int H);
 // act = silu(sum part[..][0:I]) * sum part[..][I:2I] -> dtype   (candle_nn::ops::swiglu)
 void launch_swiglu(hipStream_t st, int dtype, const float* part, int KS, long ks_stride, void* act, int M, int I);
-// out = act(sum_ks part + bias): act 0 none, 1 silu; out_dtype F32/BF16 independent of the weight dtype
+// out = act(sum_ks part + bias): act 0 none, 1 silu, 2 erf-GELU; out_dtype F32/BF16 independent of the weight dtype
 void launch_bias_act(hipStream_t st, const float* part, int KS, long ks_stride, const float* bias, int act, void* out,
                      int out_dtype, int M, int N);
 // dst[i][:] = table[idx[i]][:]  (table in `tdtype`, dst in `ddtype`)
@@ -176,7 +176,8 @@ struct ConvEpi {
     const float* bias_u;     // [U][Cout] or null: extra per-strip bias
     int Cvalid;              // 0: write all Cout columns; otherwise only columns < Cvalid (multiple of 4)
     const float* scale;      // [Cout] or null (ConvNeXt gamma)
-    int act;                 // 0 none, 1 tanh-GELU, 2 ReLU, 3 tanh(ReLU)
+    int act;                 // 0 none, 1 tanh-GELU, 2 ReLU, 3 tanh(ReLU), 4 ELU
+    int act2;                // activation of out2: 0 SnakeBeta (alpha_exp / beta_den), 1 ELU
     const int* lens;         // [U] valid GEMM rows per strip
     long S_in, S_out;        // strip lengths (rows) of the GEMM row space / of the output tensor
     int P_out, ld_out;       // output row = u * S_out + P_out + t' * r + j ; ld_out = channel stride of out / out2 / resid
@@ -217,5 +218,19 @@ void launch_small_fc(hipStream_t st, const float* W, int ldw, const float* b, co
                      int ldy);
 void launch_se_apply(hipStream_t st, int dtype, const void* x, int ldx, const float* gate, const void* resid, int ldr, const int* lens, int U,
                      int Tmax, long S, int P, int C, void* out, int ldo);
+
+// ---- k_encoder.hip (codec encoder)
+void launch_enc_init_conv(hipStream_t st, int dtype, const float* audio, const int* n_samples, int U, long max_samples, const float* w,
+                          const float* bias, long S, int P, void* out_raw, void* out_elu);
+// x = resid + [scale *] sum_ks part ; resid_out = x ; xn = LayerNorm(x) * ln_w + ln_b (skipped when ln_w is null)
+void launch_resid_layernorm(hipStream_t st, int dtype, const float* resid, const float* part, int KS, long ks_stride, const float* scale,
+                            const float* ln_w, const float* ln_b, float eps, float* resid_out, void* xn, int M, int H);
+// valid rows of f32 strips -> model-dtype strips (other rows untouched)
+void launch_rows_to_strips(hipStream_t st, int dtype, const float* src, long S_src, int P_src, const int* lens, int U, int Tmax, int C,
+                           void* dst, long S_dst, int P_dst);
+// nearest codebook entry per row: idx = argmin_r (c2[r] - dots[m][r]) (first minimum); residual[m] -= emb[idx];
+// residual_t = T(residual); codes[(u * T_cap + t) * Q + q] = idx for valid rows (m = u * S + t, t < lens[u])
+void launch_vq_argmin(hipStream_t st, int dtype, const float* dots, const float* c2, const float* emb, int bins, int cd, float* residual,
+                      void* residual_t, const int* lens, long S, int U, unsigned* codes, int T_cap, int Q, int q);
 
 }  // namespace qtts

@@ -101,7 +101,7 @@ void Model::parse_config(const std::string& config_json, const char* codec_json)
 }
 
 static bool key_is_f32(const std::string& key, int rank) {
-    return rank <= 1 || key.find("_codebook") != std::string::npos || key.find("dwconv") != std::string::npos;
+    return rank <= 1 || key.find("codebook") != std::string::npos || key.find("dwconv") != std::string::npos;
 }
 
 void Model::load_tensor(const std::string& key, const void* data, int src_dtype, const int64_t* shape, int rank, bool on_device) {
@@ -329,6 +329,7 @@ void Model::finalize() {
     }
     finalize_codec(*this);
     finalize_speaker(*this);
+    finalize_encoder(*this);
     finalized = true;
 }
 

@@ -118,6 +118,7 @@ struct Model;
 struct GenState;    // generate.cpp
 struct CodecState;  // codec.cpp
 struct SpeakerState;
+struct EncoderState;  // encoder.cpp
 
 struct Model {
     Ctx* ctx = nullptr;
@@ -135,6 +136,7 @@ struct Model {
     std::shared_ptr<GenState> gen;
     std::shared_ptr<CodecState> codec_state;
     std::shared_ptr<SpeakerState> spk_state;
+    std::shared_ptr<EncoderState> enc_state;
     double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<double> gemm_profile;      // rows of (M, N, K, launches, total us) from the last profiled generate
 

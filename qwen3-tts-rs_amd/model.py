@@ -145,6 +145,7 @@ class LoaderConfig:  # model/loader.rs:31-54
     dtype: str = "bf16"
     load_tokenizer: bool = True
     device: int = 0
+    load_encoder: bool = True   # codec encoder tensors (`encoder.*`): needed only for encode_audio / ICL voice clone
 
 
 class Model:
@@ -362,6 +363,35 @@ class Model:
         """Model::decode_output (model/generate.rs:29-143): truncate to effective lengths, chunk long sequences."""
         return self.decode_codes(output.codes, output.effective_lengths, chunk=-2, left_ctx=0)
 
+    def encode_audio(self, audio: Sequence[np.ndarray], num_quantizers: Optional[int] = None):
+        """Model::encode_audio / TokenizerV2::encode (audio/tokenizer/v2/mod.rs:164-171): 24 kHz clips -> list of
+        (frames, num_quantizers) code arrays, frames = samples // 1920."""
+        if self.codec_config is None:
+            raise QttsError(-5, "Audio tokenizer not loaded")
+        Q = int(num_quantizers or self.codec_config.get("encoder_valid_num_quantizers", 16))
+        B = len(audio)
+        ns = np.array([len(a) for a in audio], np.int32)
+        mx = int(ns.max())
+        buf = np.zeros((B, mx), np.float32)
+        for b, a in enumerate(audio):
+            buf[b, :len(a)] = a
+        cap = mx // 1920 + 1
+        codes = np.zeros((B, cap, Q), np.uint32)
+        tl = np.zeros(B, np.int32)
+        check(self.lib.qtts_encode_audio(self._m, buf.ctypes.data_as(C.c_void_p), ns.ctypes.data_as(C.c_void_p), B, mx, Q,
+                                         codes.ctypes.data_as(C.c_void_p), cap, tl.ctypes.data_as(C.c_void_p)))
+        return [codes[b, :tl[b]].copy() for b in range(B)]
+
+    def create_voice_clone_prompt_from_audio(self, audio: np.ndarray, ref_text_ids=None, x_vector_only: bool = False):
+        """Model::create_voice_clone_prompt_from_audio (model/mod.rs:643-700): speaker embedding from the clip and, in ICL
+        mode, its codes; the transcript arrives tokenised (tokenize_ref_text output)."""
+        emb = self.extract_speaker_embedding([audio])[0]
+        if x_vector_only:
+            return VoiceClonePromptItem.x_vector_only(emb)
+        if ref_text_ids is None:
+            raise QttsError(-5, "ICL mode requires ref_text to be present")
+        return VoiceClonePromptItem.icl(self.encode_audio([audio])[0], emb, ref_text_ids)
+
     def compute_mel_spectrogram(self, audio: Sequence[np.ndarray]):
         """Model::compute_mel_spectrogram (model/mod.rs:520-528): list of (frames, 128) arrays."""
         B = len(audio)
@@ -510,8 +540,8 @@ class ModelLoader:
         for path in self._tensor_files():
             with safe_open(path, framework="np") as f:
                 for key in f.keys():
-                    if key.startswith("encoder."):
-                        continue  # codec encoder weights are not part of this path
+                    if key.startswith("encoder.") and not loader.load_encoder:
+                        continue
                     try:
                         arr = f.get_tensor(key)
                     except TypeError:  # bf16 is not a numpy dtype: read the raw bits through torch
@@ -524,7 +554,7 @@ class ModelLoader:
 
 
 def synthetic_model(shape: str, dtype: str = "bf16", seed: int = 20261111, model_type: str = "custom_voice", codec: bool = True,
-                    talker: bool = True, device: int = 0, round_to_bf16: bool = False):
+                    talker: bool = True, device: int = 0, round_to_bf16: bool = False, encoder: bool = False):
     """Random-init model of a named shape set (see synth.py).  Returns (Model, config, codec_config, template)."""
     from . import synth
     cfg, ccfg, tmpl = synth.shape_set(shape, model_type)
@@ -534,6 +564,8 @@ def synthetic_model(shape: str, dtype: str = "bf16", seed: int = 20261111, model
         keys += synth.talker_keys(cfg) + synth.speaker_keys(cfg)
     if codec:
         keys += synth.codec_keys(ccfg)
+    if encoder:
+        keys += synth.encoder_keys()
     for k, a in synth.iter_weights(keys, seed):
         if round_to_bf16:
             a = round_bf16(a)

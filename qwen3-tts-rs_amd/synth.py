@@ -303,6 +303,41 @@ def codec_keys(codec_cfg):
     return ks
 
 
+def encoder_keys():
+    """Codec encoder tensors (fixed architecture: audio/encoder/v2.rs:30-49, seanet.rs:93-150, quantizer.rs:86-172)."""
+    P = "encoder."
+    ks = []
+
+    def conv(name, cout, cin, k, gain="1.0", bias=True):
+        out = [(P + name + ".weight", (cout, cin, k), f"fanin:{gain}")]
+        if bias:
+            out.append((P + name + ".bias", (cout,), "normal:0.02"))
+        return out
+
+    ks += conv("encoder.layers.0.conv", 64, 1, 7)
+    C, idx = 64, 1
+    for r in (4, 5, 6, 8):
+        ks += conv(f"encoder.layers.{idx}.block.1.conv", C // 2, C, 3) + conv(f"encoder.layers.{idx}.block.3.conv", C, C // 2, 1, "0.5")
+        ks += conv(f"encoder.layers.{idx + 2}.conv", 2 * C, C, 2 * r)
+        C *= 2
+        idx += 3
+    ks += conv(f"encoder.layers.{idx + 1}.conv", 512, C, 3)
+    for i in range(8):
+        L = P + f"encoder_transformer.layers.{i}."
+        ks += [(L + f"self_attn.{n}_proj.weight", (512, 512), "fanin:1.0") for n in "qkvo"]
+        ks += [(L + "mlp.fc1.weight", (2048, 512), "fanin:1.0"), (L + "mlp.fc2.weight", (512, 2048), "fanin:1.0"),
+               (L + "input_layernorm.weight", (512,), "ones:0.1"), (L + "input_layernorm.bias", (512,), "normal:0.02"),
+               (L + "post_attention_layernorm.weight", (512,), "ones:0.1"), (L + "post_attention_layernorm.bias", (512,), "normal:0.02"),
+               (L + "self_attn_layer_scale.scale", (512,), "const:0.1:0.01"), (L + "mlp_layer_scale.scale", (512,), "const:0.1:0.01")]
+    ks += conv("downsample.conv", 512, 512, 4, bias=False)
+    for grp, n in (("semantic", 1), ("acoustic", 31)):
+        Q = P + f"quantizer.{grp}_residual_vector_quantizer."
+        ks += [(Q + "input_proj.weight", (256, 512, 1), "fanin:1.0"), (Q + "output_proj.weight", (512, 256, 1), "fanin:1.0")]
+        for i in range(n):
+            ks += [(Q + f"layers.{i}.codebook.embed_sum", (2048, 256), "normal:1.0"), (Q + f"layers.{i}.codebook.cluster_usage", (2048,), "usage")]
+    return ks
+
+
 def iter_weights(keys, seed: int):
     for key, shape, kind in keys:
         yield key, make_tensor(key, shape, kind, seed)
