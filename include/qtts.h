@@ -149,6 +149,19 @@ int qtts_bench_stream(qtts_ctx* ctx, long bytes, int blocks, int pattern, int un
 int qtts_codec_decode(qtts_model* m, const uint32_t* codes, const int* lens, int B, int T_max, int chunk, int left_ctx,
                       float* wav_out, int64_t wav_stride, int64_t* wav_lens);
 
+/* Streaming decode session.  No counterpart in the reference, whose only incremental mode is chunked_decode
+ * (audio/decoder/v2.rs:250-286: every chunk restarts with 32 frames of context, so its output differs from a whole decode).
+ * Here the concatenation of the pushes' samples EQUALS qtts_codec_decode(chunk = 0) of the concatenated codes: the
+ * transformer continues from a per-row ring of keys/values and the conv stack re-decodes the few context frames its
+ * receptive field spans.  All B rows advance together.  A push of n frames (1 <= n <= max_chunk_frames), codes [B][n][Q],
+ * writes to wav_out [B][wav_stride] the samples those frames decide: up * n - tail for the first push (1920 n - 555 at the
+ * default config), up * n for every later one; *n_samples receives that count. */
+typedef struct qtts_codec_stream qtts_codec_stream;
+int qtts_codec_stream_open(qtts_model* m, int B, int max_chunk_frames, qtts_codec_stream** out);
+int qtts_codec_stream_push(qtts_codec_stream* s, const uint32_t* codes, int n_frames, float* wav_out, int64_t wav_stride,
+                           int64_t* n_samples);
+void qtts_codec_stream_close(qtts_codec_stream* s);
+
 /* TokenizerV2::encode / Model::encode_audio (audio/tokenizer/v2/mod.rs:164-171, audio/encoder/v2.rs:87-120): 24 kHz clips
  * audio [B][max_samples] -> codes_out [B][T_cap][num_quantizers], T_out[b] = n_samples[b] / 1920 frames.  Needs the speech
  * tokenizer's `encoder.*` tensors (acoustic codebooks beyond num_quantizers - 1 may be omitted). */

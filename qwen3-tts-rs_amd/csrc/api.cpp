@@ -145,6 +145,23 @@ int qtts_codec_decode(qtts_model* m, const uint32_t* codes, const int* lens, int
     QTTS_API_END
 }
 
+int qtts_codec_stream_open(qtts_model* m, int B, int max_chunk_frames, qtts_codec_stream** out) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(m && out, ERR_BAD_ARG, "qtts_codec_stream_open: null argument");
+    *out = reinterpret_cast<qtts_codec_stream*>(codec_stream_open(m->m, B, max_chunk_frames));
+    QTTS_API_END
+}
+
+int qtts_codec_stream_push(qtts_codec_stream* s, const uint32_t* codes, int n_frames, float* wav_out, int64_t wav_stride,
+                           int64_t* n_samples) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(s && codes && wav_out && n_samples, ERR_BAD_ARG, "qtts_codec_stream_push: null argument");
+    codec_stream_push(*reinterpret_cast<CodecStream*>(s), codes, n_frames, wav_out, wav_stride, n_samples);
+    QTTS_API_END
+}
+
+void qtts_codec_stream_close(qtts_codec_stream* s) { codec_stream_close(reinterpret_cast<CodecStream*>(s)); }
+
 int qtts_encode_audio(qtts_model* m, const float* audio, const int* n_samples, int B, int max_samples, int num_quantizers,
                       uint32_t* codes_out, int T_cap, int* T_out) {
     QTTS_API_BEGIN

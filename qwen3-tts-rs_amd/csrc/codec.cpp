@@ -5,6 +5,7 @@
 // fused epilogue (k_codec.hip).  Weights are rearranged once at load time into [N][taps * Cin] rows with the
 // channel counts padded to multiples of 64; padded channels carry zeros end to end.
 #include <algorithm>
+#include <cstdio>
 #include <cmath>
 #include <cstring>
 
@@ -48,6 +49,18 @@ struct CodecState {
     // run-time buffers (grown on demand, kept between calls)
     Workspace ws;
     DevBuf kv, toks, meta, codes, A, Bf, R, Rf, acc, wav;
+};
+
+// Streaming decode session: the transformer's keys/values live in a ring per row, and the last `ctx_cap` frames of codes and
+// of transformer output are kept so that the convolutional stack of the next push sees real history instead of zero padding.
+struct CodecStream {
+    Model* m = nullptr;
+    int B = 0, max_chunk = 0, ctx_cap = 0, ring_pages = 0;
+    long frames = 0;                  // frames pushed so far (every row advances together)
+    int C = 0;                        // context frames held (min(frames, ctx_cap))
+    std::vector<uint32_t> ctx_codes;  // [B][C][Q]
+    DevBuf latent_ctx;                // [B][ctx_cap][latP] model dtype
+    DevBuf kv;                        // [layers][(B + 1) * ring_pages] pages; row B takes the writes of rows that are not tokens
 };
 
 void finalize_codec(Model& m) {
@@ -247,16 +260,47 @@ struct Decoder {
         int ldx = 0;
     } pend;
     void gemm(const GemmW& g, const void* X, long M, int ldx) { pend = Pending{&g, X, M, ldx}; }
+    // QTTS_CODEC_PROFILE=1: HIP events around every conv launch, one table per group on stderr (measurement aid)
+    struct Prof {
+        hipEvent_t a, b;
+        long M;
+        int N, K, taps, dil;
+    };
+    std::vector<Prof> prof;
+    bool profiling = getenv("QTTS_CODEC_PROFILE") != nullptr;
     void epilogue(ConvEpi e) {
         QTTS_CHECK(pend.g != nullptr && e.M == pend.M && e.N == pend.g->N, ERR_STATE, "codec decode: epilogue does not match the pending GEMM");
         e.acc = nullptr;
+        Prof pr{};
+        if (profiling) {
+            pr = Prof{nullptr, nullptr, pend.M, pend.g->N, pend.g->K, pend.g->taps, pend.g->dil};
+            QTTS_HIP(hipEventCreate(&pr.a));
+            QTTS_HIP(hipEventCreate(&pr.b));
+            QTTS_HIP(hipEventRecord(pr.a, st));
+        }
         launch_gemm_rows_epi(st, dt, pend.g->w.p, pend.X, pend.g->K, pend.ldx, pend.g->taps, (long)pend.g->dil * pend.ldx, e);
+        if (profiling) {
+            QTTS_HIP(hipEventRecord(pr.b, st));
+            prof.push_back(pr);
+        }
         pend = Pending{};
     }
-    void run_group(const uint32_t* d_codes, int T_max, const std::vector<Piece>& ps, float* wav_out, int64_t wav_stride);
+    void report() {
+        for (Prof& p : prof) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, p.a, p.b);
+            const double fl = 2.0 * (double)p.M * p.N * p.K;
+            fprintf(stderr, "codec conv M=%9ld N=%5d K=%5d taps=%2d dil=%d  %8.3f ms  %7.1f TFLOP/s  in+out %6.2f GB/s-equiv\n", p.M, p.N, p.K, p.taps,
+                    p.dil, ms, fl / ms / 1e9, ((double)p.M * (p.K / p.taps + p.N) * es) / ms / 1e6);
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
+        }
+        prof.clear();
+    }
+    void run_group(const uint32_t* d_codes, int T_max, const std::vector<Piece>& ps, float* wav_out, int64_t wav_stride, CodecStream* sc = nullptr);
 };
 
-void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Piece>& ps, float* wav_out, int64_t wav_stride) {
+void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Piece>& ps, float* wav_out, int64_t wav_stride, CodecStream* sc) {
     const CodecCfg& c = m.codec;
     const int U = (int)ps.size();
     int Tm = 0;
@@ -343,13 +387,17 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         s.ws.attn.ensure(rp * nq * es);
         s.ws.act.ensure(rp * c.inter * es);
         // pages: one private range per strip + one shared dump page for the padding rows
-        const int pp = (Tm + PAGE - 1) / PAGE;
+        const int pp = sc ? sc->ring_pages : (Tm + PAGE - 1) / PAGE;
+        // a streaming push holds C context frames in front of the new ones: only the new frames are tokens, at the
+        // positions they have in the whole sequence; their keys/values join the session's ring
+        const int Cs = sc ? sc->C : 0;
+        const long pos0 = sc ? sc->frames - Cs : 0;
         std::vector<Tok> toks((size_t)M);
         for (int u = 0; u < U; ++u)
             for (long r = 0; r < S[0]; ++r) {
                 Tok& t = toks[(size_t)(u * S[0] + r)];
-                if (r < L[0][(size_t)u]) {
-                    const int pos = (int)r, lo = std::max(0, pos + 1 - c.window);
+                if (r >= Cs && r < L[0][(size_t)u]) {
+                    const int pos = (int)(pos0 + r), lo = std::max(0, pos + 1 - c.window);
                     t = Tok{u, pos, lo, pos + 1 - lo};
                 } else {
                     const int slot = (int)((u * S[0] + r) % PAGE);
@@ -357,14 +405,21 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
                 }
             }
         const size_t page_elems = (size_t)2 * c.kv_heads * PAGE * c.head_dim;
-        s.kv.ensure(((size_t)U + 1) * pp * page_elems * es);  // row U: dump pages for the padding rows
+        if (!sc) s.kv.ensure(((size_t)U + 1) * pp * page_elems * es);  // row U: dump pages for the padding rows
         s.toks.ensure(toks.size() * sizeof(Tok));
         QTTS_HIP(hipMemcpyAsync(s.toks.p, toks.data(), toks.size() * sizeof(Tok), hipMemcpyHostToDevice, st));
         QTTS_HIP(hipStreamSynchronize(st));  // toks is a local
+        // one-shot decodes reuse one layer's worth of pages for every layer; a session keeps all layers
         KVView kv{s.kv.p, 0, PAGE, c.kv_heads, c.head_dim, pp, nullptr};
-        if (s.xf.max_pos < std::max(Tm, PAGE)) {
+        if (sc) {
+            kv.base = sc->kv.p;
+            kv.layer_stride = ((size_t)U + 1) * pp * page_elems;
+            kv.page_mask = pp - 1;
+        }
+        const int pos_end = (int)(pos0 + Tm);
+        if (s.xf.max_pos < std::max(pos_end, PAGE)) {
             int n = 256;
-            while (n < Tm) n *= 2;
+            while (n < pos_end) n *= 2;
             std::vector<float> cs, sn;
             rope_table_simple(c.head_dim, c.rope_theta, n, cs, sn);
             s.xf.cos.alloc(cs.size() * 4);
@@ -379,7 +434,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         run.gemm(s.in_proj.w.p, s.Bf.p, M, Hd, s.latP, ks, s.latP);
         launch_resid_norm(st, dt, nullptr, s.ws.part.as<float>(), ks, run.kstride(M, Hd), s.in_proj.bias.as<float>(), nullptr,
                           s.xf.layers[0].ln1, c.eps, s.ws.x.as<float>(), s.ws.xn.p, nullptr, M, Hd);
-        run.stack(s.xf, M, s.toks.as<Tok>(), kv, s.ws.xn.p, nullptr, false);
+        run.stack(s.xf, M, s.toks.as<Tok>(), kv, s.ws.xn.p, nullptr, sc != nullptr);
         // output_proj (+bias) -> strips without padding (the next op is a kernel == stride transposed conv)
         ks = run.ks_for(M, s.latP, Hd);
         run.gemm(s.out_proj.w.p, s.ws.xn.p, M, s.latP, Hd, ks, Hd);
@@ -392,6 +447,15 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         e.acc = acc; e.M = M0; e.N = s.latP; e.r = 1; e.Cout = s.latP; e.bias = s.out_proj.bias.as<float>();
         e.lens = d_len(0); e.S_in = S[0]; e.S_out = S[0]; e.P_out = 0; e.ld_out = s.latP; e.out = s.A.p;
         launch_conv_epilogue(st, dt, e);
+        if (sc) {
+            // rows [0, C) of every strip: the transformer output of the previous pushes; then keep this push's tail
+            const size_t rowb = (size_t)s.latP * es, strip = (size_t)S[0] * rowb, slot = (size_t)sc->ctx_cap * rowb;
+            if (Cs > 0)
+                QTTS_HIP(hipMemcpy2DAsync(s.A.p, strip, sc->latent_ctx.p, slot, (size_t)Cs * rowb, (size_t)U, hipMemcpyDeviceToDevice, st));
+            const int keep = std::min(Tm, sc->ctx_cap);
+            QTTS_HIP(hipMemcpy2DAsync(sc->latent_ctx.p, slot, (const char*)s.A.p + (size_t)(Tm - keep) * rowb, strip, (size_t)keep * rowb, (size_t)U,
+                                      hipMemcpyDeviceToDevice, st));
+        }
     }
     // ================= upsample stages: the current tensor lives in A with Pcur leading rows per strip =================
     int Pcur = 0;
@@ -502,7 +566,10 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
     const long up_total = c.total_upsample();
     for (int u = 0; u < U; ++u) {
         const Piece& p = ps[(size_t)u];
-        const long drop = (long)p.drop_frames * up_total, n = L[(size_t)last][(size_t)u] - drop;
+        // a streaming push re-decodes C context frames: everything up to the end of the previous push's output goes
+        long drop = (long)p.drop_frames * up_total;
+        if (sc && sc->C > 0) drop = (long)sc->C * up_total - ((long)Tm * up_total - L[(size_t)last][(size_t)u]);
+        const long n = L[(size_t)last][(size_t)u] - drop;
         QTTS_CHECK(n >= 0, ERR_SHAPE, "codec decode: chunk shorter than its context");
         QTTS_CHECK(p.out_off + n <= wav_stride, ERR_SHAPE, "codec decode: wav_stride too small");
         if (n > 0)
@@ -513,6 +580,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
     float ms = 0;
     QTTS_HIP(hipEventElapsedTime(&ms, ev0, ev1));
     m.timing[6] += ms;
+    if (profiling) report();
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
 }
@@ -587,6 +655,104 @@ void run_codec_decode(Model& m, const uint32_t* codes, const int* lens, int B, i
         dec.run_group(s.codes.as<uint32_t>(), T_max, grp, wav_out, wav_stride);
         i += n;
     }
+}
+
+// ---- streaming decode -----------------------------------------------------------------------------------------------
+// The decoder is causal, so the samples of a prefix never change when more frames arrive (a prefix of n frames decides
+// samples [0, up * n - tail), tail = 555 at the default config).  The reference has no streaming decode; its chunked
+// decode (audio/decoder/v2.rs:250-286) restarts the transformer and the convs with 32 frames of context and is inexact.
+// Here the transformer continues from its ring of keys/values, and the conv stack re-decodes just enough context
+// frames to cover its receptive field, so the concatenated pushes equal one whole decode.
+
+// frames of transformer output the conv stack needs in front of a push so that the first sample it has to emit is exact
+static int conv_context_frames(const CodecCfg& c) {
+    long up = c.total_upsample(), L = 1;
+    for (int r : c.upsampling_ratios) L *= r;
+    for (int r : c.upsample_rates) L = (L - 1) * r;
+    long need = (up - L) + 6;  // the first emitted sample sits `tail` samples before the context boundary; final conv k = 7
+    for (size_t b = c.upsample_rates.size(); b-- > 0;) {
+        need += 6 * (1 + 3 + 9);                                      // three residual units, k = 7, dilations 1, 3, 9
+        need = (need + c.upsample_rates[b] - 1) / c.upsample_rates[b];  // transposed conv: output j reads inputs j / r and j / r + 1
+    }
+    need += 6;  // decoder.0, k = 7
+    for (size_t i = c.upsampling_ratios.size(); i-- > 0;) {
+        need += 6;  // ConvNeXt depthwise k = 7
+        need = (need + c.upsampling_ratios[i] - 1) / c.upsampling_ratios[i];
+    }
+    return (int)need + 2;  // + pre_conv's two frames of code history
+}
+
+CodecStream* codec_stream_open(Model& m, int B, int max_chunk) {
+    QTTS_CHECK(m.finalized && m.codec_state, ERR_STATE, "codec weights are not loaded");
+    QTTS_CHECK(B >= 1 && B <= 4096 && max_chunk >= 1 && max_chunk <= 8192, ERR_BAD_ARG, "codec stream: bad batch or chunk size");
+    QTTS_HIP(hipSetDevice(m.ctx->device));
+    const CodecCfg& c = m.codec;
+    CodecState& s = *m.codec_state;
+    std::unique_ptr<CodecStream> sc(new CodecStream());
+    sc->m = &m;
+    sc->B = B;
+    sc->max_chunk = max_chunk;
+    sc->ctx_cap = conv_context_frames(c);
+    // the ring must hold the window of the oldest token of a push while the newest one is written
+    int pages = 1;
+    while ((long)pages * PAGE < (long)sc->ctx_cap + max_chunk + c.window + PAGE) pages *= 2;
+    sc->ring_pages = pages;
+    const size_t es = dtype_size(m.dtype);
+    const size_t page_elems = (size_t)2 * c.kv_heads * PAGE * c.head_dim;
+    sc->kv.alloc((size_t)c.layers * ((size_t)B + 1) * pages * page_elems * es);
+    sc->latent_ctx.alloc((size_t)B * sc->ctx_cap * s.latP * es);
+    return sc.release();
+}
+
+void codec_stream_close(CodecStream* sc) {
+    if (!sc) return;
+    (void)hipSetDevice(sc->m->ctx->device);
+    (void)hipStreamSynchronize(sc->m->ctx->stream);
+    delete sc;
+}
+
+// codes [B][n][Q]: the next n frames of every row.  wav_out [B][wav_stride] receives the samples these frames decide:
+// up * n - tail for the first push, up * n afterwards; *n_samples is that count.
+void codec_stream_push(CodecStream& sc, const uint32_t* codes, int n, float* wav_out, int64_t wav_stride, int64_t* n_samples) {
+    Model& m = *sc.m;
+    QTTS_CHECK(m.finalized && m.codec_state, ERR_STATE, "codec weights are not loaded");
+    QTTS_CHECK(n >= 1 && n <= sc.max_chunk, ERR_BAD_ARG, "codec stream: push is empty or longer than the session's max_chunk");
+    QTTS_HIP(hipSetDevice(m.ctx->device));
+    CodecState& s = *m.codec_state;
+    const CodecCfg& c = m.codec;
+    const int B = sc.B, Q = s.Q, C = sc.C, T = C + n;
+    for (size_t i = 0; i < (size_t)B * n * Q; ++i) QTTS_CHECK(codes[i] < (uint32_t)s.csize, ERR_BAD_ARG, "codec stream: code id out of range");
+    long L = T;
+    for (int r : c.upsampling_ratios) L *= r;
+    for (int r : c.upsample_rates) L = (L - 1) * r;
+    const long up = c.total_upsample();
+    const long out = C > 0 ? (long)n * up : L;
+    QTTS_CHECK(out >= 1, ERR_SHAPE, "codec stream: the first push is too short to decide any sample");
+    QTTS_CHECK(out <= wav_stride, ERR_SHAPE, "codec stream: wav_stride too small");
+    QTTS_CHECK(make_geometry(c, s, B, T).bytes(dtype_size(m.dtype)) <= ((size_t)96 << 30), ERR_OOM,
+               "codec stream: batch x chunk needs more than 96 GB of scratch; push fewer frames at a time");
+    // context codes in front of the new ones
+    std::vector<uint32_t> all((size_t)B * T * Q);
+    for (int b = 0; b < B; ++b) {
+        uint32_t* dst = &all[(size_t)b * T * Q];
+        if (C > 0) std::memcpy(dst, &sc.ctx_codes[(size_t)b * C * Q], (size_t)C * Q * 4);
+        std::memcpy(dst + (size_t)C * Q, codes + (size_t)b * n * Q, (size_t)n * Q * 4);
+    }
+    s.codes.ensure(all.size() * 4);
+    QTTS_HIP(hipMemcpy(s.codes.p, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+    std::vector<Piece> ps;
+    for (int b = 0; b < B; ++b) ps.push_back(Piece{b, 0, T, 0, 0});
+    m.timing[6] = 0;
+    Decoder dec(m);
+    dec.run_group(s.codes.as<uint32_t>(), T, ps, wav_out, wav_stride, &sc);
+    // session state for the next push
+    const int Cn = std::min(T, sc.ctx_cap);
+    std::vector<uint32_t> ctx((size_t)B * Cn * Q);
+    for (int b = 0; b < B; ++b) std::memcpy(&ctx[(size_t)b * Cn * Q], &all[((size_t)b * T + (T - Cn)) * Q], (size_t)Cn * Q * 4);
+    sc.ctx_codes.swap(ctx);
+    sc.C = Cn;
+    sc.frames += n;
+    *n_samples = out;
 }
 
 }  // namespace qtts

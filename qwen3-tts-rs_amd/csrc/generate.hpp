@@ -12,6 +12,11 @@ void finalize_codec(Model& m);
 void run_codec_decode(Model& m, const uint32_t* codes, const int* lens, int B, int T_max, int chunk, int left_ctx, float* wav_out,
                       int64_t wav_stride, int64_t* wav_lens);
 
+struct CodecStream;  // streaming decode session (codec.cpp)
+CodecStream* codec_stream_open(Model& m, int B, int max_chunk);
+void codec_stream_push(CodecStream& sc, const uint32_t* codes, int n, float* wav_out, int64_t wav_stride, int64_t* n_samples);
+void codec_stream_close(CodecStream* sc);
+
 void finalize_encoder(Model& m);
 void run_encode_audio(Model& m, const float* audio, const int* n_samples, int B, int max_samples, int Q, uint32_t* codes_out, int T_cap,
                       int* T_out);

@@ -18,6 +18,7 @@ struct KVView {
     size_t layer_stride;  // elements
     int page_tokens, nkv, d, max_pages;
     const int* page_table;  // null: row r owns pages [r * max_pages, (r + 1) * max_pages)
+    int page_mask = 0x7fffffff;  // ring caches: max_pages is a power of two and page_mask = max_pages - 1 (positions wrap)
 };
 
 // ---- k_gemm.hip

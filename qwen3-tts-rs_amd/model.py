@@ -363,6 +363,10 @@ class Model:
         """Model::decode_output (model/generate.rs:29-143): truncate to effective lengths, chunk long sequences."""
         return self.decode_codes(output.codes, output.effective_lengths, chunk=-2, left_ctx=0)
 
+    def open_codec_stream(self, batch: int, max_chunk_frames: int) -> "CodecStream":
+        """Streaming decode session: the concatenated pushes equal one whole `decode_codes` of the concatenated codes."""
+        return CodecStream(self, batch, max_chunk_frames)
+
     def encode_audio(self, audio: Sequence[np.ndarray], num_quantizers: Optional[int] = None):
         """Model::encode_audio / TokenizerV2::encode (audio/tokenizer/v2/mod.rs:164-171): 24 kHz clips -> list of
         (frames, num_quantizers) code arrays, frames = samples // 1920."""
@@ -499,6 +503,44 @@ class Model:
         reqs = [GenerationRequest(text_ids=t, language=language, speaker=speaker,
                                   seed=None if seed is None else seed + i) for i, t in enumerate(text_ids_list)]
         return self._finish(self.generate(reqs, sampling, mx), decode)
+
+
+class CodecStream:
+    """Handle of a streaming decode session (qtts_codec_stream_*).  The reference has no counterpart: its chunked decode
+    restarts every chunk with 32 frames of context and is not equal to a whole decode."""
+
+    def __init__(self, model: "Model", batch: int, max_chunk_frames: int):
+        self.model, self.batch, self.max_chunk = model, int(batch), int(max_chunk_frames)
+        self._s = C.c_void_p()
+        check(model.lib.qtts_codec_stream_open(model._m, self.batch, self.max_chunk, C.byref(self._s)))
+
+    def push(self, codes: np.ndarray) -> np.ndarray:
+        """codes (batch, n, quantizers): the next n frames of every row -> (batch, samples) decided by them."""
+        if self._s is None:
+            raise QttsError(-5, "codec stream is closed")
+        c = np.ascontiguousarray(codes, np.uint32)
+        if c.ndim == 2:
+            c = c[None]
+        B, n, Q = c.shape
+        if B != self.batch:
+            raise QttsError(-1, f"codec stream was opened for batch {self.batch}, got {B}")
+        stride = n * self.model.total_upsample()
+        wav = np.empty((B, stride), np.float32)
+        ns = C.c_int64(0)
+        check(self.model.lib.qtts_codec_stream_push(self._s, c.ctypes.data_as(C.c_void_p), n, wav.ctypes.data_as(C.c_void_p), stride,
+                                                     C.byref(ns)))
+        return wav[:, :ns.value]
+
+    def close(self):
+        if self._s is not None:
+            self.model.lib.qtts_codec_stream_close(self._s)
+            self._s = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 class ModelLoader:
