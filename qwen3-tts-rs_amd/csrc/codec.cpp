@@ -545,7 +545,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
                 e.resid_f32 = s.Rf.as<float>(); e.lens = d_len(so); e.S_in = S[(size_t)so]; e.S_out = S[(size_t)so]; e.P_out = Pn; e.ld_out = CPo;
                 const Snake& nx = u < 2 ? blk.u[u + 1].a1 : (b + 1 < nb ? s.blocks[(size_t)b + 1].s0 : s.sfinal);
                 e.alpha_exp = nx.a.as<float>(); e.beta_den = nx.den.as<float>();
-                e.out_f32 = s.Rf.as<float>();
+                e.out_f32 = u < 2 ? s.Rf.as<float>() : nullptr;  // after the last unit only the activated copy is read again
                 e.out2 = s.A.p;
                 epilogue(e);
             }

@@ -97,7 +97,7 @@ __device__ __forceinline__ void conv_epi_apply(const ConvEpi& e, long u, int tp,
         T* o = (T*)e.out2 + o_off;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float x = e.out_f32 ? v[q] : to_f32<T>(from_f32<T>(v[q]));
+            const float x = (e.out_f32 || e.resid_f32) ? v[q] : to_f32<T>(from_f32<T>(v[q]));
             o[q] = from_f32<T>(x > 0.f ? x : expf(x) - 1.0f);
         }
     } else if (e.out2) {
@@ -107,8 +107,8 @@ __device__ __forceinline__ void conv_epi_apply(const ConvEpi& e, long u, int tp,
         T* o = (T*)e.out2 + o_off;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            // SnakeBeta in f32 on the value the next op would read: the stored (rounded) one unless an f32 copy is kept
-            const float x = e.out_f32 ? v[q] : to_f32<T>(from_f32<T>(v[q]));
+            // SnakeBeta in f32 on the value the next op would read: the stored (rounded) one unless the stream is kept in f32
+            const float x = (e.out_f32 || e.resid_f32) ? v[q] : to_f32<T>(from_f32<T>(v[q]));
             const float sn = snake_sin<T>(x * al[q]);
             o[q] = from_f32<T>(x + snake_div<T>(sn * sn, den[q]));
         }

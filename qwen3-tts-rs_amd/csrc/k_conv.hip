@@ -155,6 +155,155 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
     }
 }
 
+// Second tiling for long inputs: the four waves form a WM x WN grid, each wave owns 16*MT rows x 16*NT columns, so a weight
+// fragment feeds MT MFMAs and an input fragment NT MFMAs.  At MT = 8, NT = 4 the LDS reads per MFMA are a quarter and the
+// weight loads per MFMA half of those of the kernel above (where all four waves read the same input fragments), which is
+// what bounds it.  The input channels are walked in phases of `cph` channels so that the tile of 256 rows + halo stays in LDS
+// whatever the layer's width; the weight stream is prefetched across phase boundaries.
+template <typename T, int MT, int NT, int WN>
+__global__ __launch_bounds__(256) void conv_tile_kernel(const T* __restrict__ W, const T* __restrict__ X, int K, int C, int taps, int dil,
+                                                        int cph, ConvEpi e) {
+    using F = CFrag<T>;
+    extern __shared__ uint4 tile[];
+    constexpr int WM = 4 / WN;
+    constexpr int RT = 16 * MT * WM;
+    constexpr int VPE = 16 / (int)sizeof(T);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const long m0 = (long)blockIdx.y * RT;
+    const int vpr = cph / VPE;  // vectors per tile row (a multiple of 8)
+    const int rows_t = RT + (taps - 1) * dil;
+    const int nb = blockIdx.x * (16 * NT * WN);
+    const int cpp = cph / F::CHUNK, per_phase = taps * cpp, nC = (C / cph) * per_phase;
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    constexpr int PF = 2;  // weight chunks in flight per wave
+    F a[PF][NT];
+    const T* wrow[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wrow[j] = W + (size_t)(nb + (j * WN + wn) * 16 + r) * K + g * F::EPL;
+    // chunk q of the K walk: phase ph, tap, chunk c inside the phase's channels
+    auto woff = [&](int q) {
+        const int ph = q / per_phase, rem = q - ph * per_phase;
+        const int tap = rem / cpp, c = rem - tap * cpp;
+        return (size_t)tap * C + (size_t)ph * cph + (size_t)c * F::CHUNK;
+    };
+    {
+        const size_t o = woff(0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) a[0][j].load(wrow[j] + o);
+    }
+    for (int q0 = 0; q0 < nC; q0 += PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            const int q = q0 + s;
+            if (q >= nC) break;
+            const int ph = q / per_phase, rem = q - ph * per_phase;
+            if (rem == 0) {  // new phase: its channels of the input tile
+                __syncthreads();
+                const T* src = X + m0 * C + (size_t)ph * cph;
+                for (int v = threadIdx.x; v < rows_t * vpr; v += 256) {
+                    const int row = v / vpr, col = v - row * vpr;
+                    tile[row * vpr + (col ^ (row & 7))] = *reinterpret_cast<const uint4*>(src + (long)row * C + col * VPE);
+                }
+                __syncthreads();
+            }
+            if (q + 1 < nC) {
+                const size_t o = woff(q + 1);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) a[(s + 1) % PF][j].load(wrow[j] + o);
+            }
+            const int tap = rem / cpp, c = rem - tap * cpp;
+            const int vb = (c * F::CHUNK + g * F::EPL) / VPE;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = wm * (16 * MT) + 16 * i + r + tap * dil;
+                const uint4 h0 = tile[row * vpr + (vb ^ (row & 7))];
+                const uint4 h1 = tile[row * vpr + ((vb + 1) ^ (row & 7))];
+                F b;
+                __builtin_memcpy(&b, &h0, 16);
+                __builtin_memcpy((char*)&b + 16, &h1, 16);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[s][j], b, acc[i][j]);
+            }
+        }
+    }
+    // epilogue through LDS, PT column tiles of every wave per pass (see conv_halo_kernel)
+    constexpr int PT = NT % 2 == 0 ? 2 : 1;
+    constexpr int CP = 16 * WN * PT, OP = CP + 4;
+    float* otile = reinterpret_cast<float*>(tile);
+    __shared__ int row_u[RT], row_tp[RT];
+    for (int t = threadIdx.x; t < RT; t += 256) {
+        const long m = m0 + t;
+        int uu = 0, tt = -1;
+        if (m < e.M) {
+            const long u = m / e.S_in;
+            const int tp = (int)(m - u * e.S_in);
+            uu = (int)u;
+            tt = tp < e.lens[u] ? tp : -1;
+        }
+        row_u[t] = uu;
+        row_tp[t] = tt;
+    }
+#pragma unroll
+    for (int p = 0; p < NT / PT; ++p) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int jj = 0; jj < PT; ++jj)
+                *reinterpret_cast<f32x4_t*>(otile + (wm * (16 * MT) + 16 * i + r) * OP + (jj * WN + wn) * 16 + 4 * g) = acc[i][p * PT + jj];
+        __syncthreads();
+        constexpr int GPR = CP / 4;
+        for (int idx = threadIdx.x; idx < RT * GPR; idx += 256) {
+            const int row = idx / GPR, c4 = idx - row * GPR;
+            const int tp = row_tp[row];
+            if (tp < 0) continue;
+            const long u = row_u[row];
+            const float4 a4 = *reinterpret_cast<const float4*>(otile + row * OP + 4 * c4);
+            float v[4] = {a4.x, a4.y, a4.z, a4.w};
+            conv_epi_apply<T>(e, u, tp, nb + p * CP + 4 * c4, v);
+        }
+    }
+}
+
+template <typename T, int MT, int NT, int WN>
+void launch_tile(hipStream_t st, const T* W, const T* X, int K, int C, int taps, int dil, int cph, const ConvEpi& e) {
+    constexpr int RT = 16 * MT * (4 / WN);
+    constexpr int PT = NT % 2 == 0 ? 2 : 1;
+    const size_t lds = std::max((size_t)(RT + (taps - 1) * dil) * cph * sizeof(T), (size_t)RT * (16 * WN * PT + 4) * 4);
+    const long gy = (e.M + RT - 1) / RT;
+    auto* fn = conv_tile_kernel<T, MT, NT, WN>;
+    QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fn, dim3(e.N / (16 * NT * WN), (unsigned)gy), dim3(256), lds, st, W, X, K, C, taps, dil, cph, e);
+}
+
+// 256 x 128 or 256 x 192 tiles.  The choice depends on the layer only, never on the number of rows: a row's result must not
+// depend on what else is in the batch (the two kernels walk K in different orders).
+template <typename T>
+bool try_tile(hipStream_t st, const T* W, const T* X, int K, int C, int taps, int dil, const ConvEpi& e) {
+    static const bool off = getenv("QTTS_CONV_TILE2") && atoi(getenv("QTTS_CONV_TILE2")) == 0;
+    static const long min_rows = getenv("QTTS_CONV_TILE2_ROWS") ? atol(getenv("QTTS_CONV_TILE2_ROWS")) : 1;
+    static const long min_k = getenv("QTTS_CONV_TILE2_K") ? atol(getenv("QTTS_CONV_TILE2_K")) : 5000;
+    const long halo = (long)(taps - 1) * dil;
+    // one block per CU (348 registers per lane): nothing hides its tile load and its epilogue, so it only wins where the K walk
+    // is long (measured on the vocoder: 7-tap convs over >= 768 channels 27 % faster, everything narrower slower)
+    if (off || e.M < min_rows || halo > 128 || (e.M + 255) / 256 > 0x7fffffffL || (long)taps * C < min_k) return false;
+    // channels per phase: as many as keep the tile of 256 rows + halo within 96 KB
+    int cph = 0;
+    for (int c = C; c >= 64; c -= 64)
+        if (C % c == 0 && (size_t)(256 + halo) * c * sizeof(T) <= (size_t)96 * 1024) { cph = c; break; }
+    if (cph == 0) return false;
+    if (e.N % 128 == 0) launch_tile<T, 8, 4, 2>(st, W, X, K, C, taps, dil, cph, e);
+    else if (e.N % 192 == 0) launch_tile<T, 8, 6, 2>(st, W, X, K, C, taps, dil, cph, e);
+    else return false;
+    return true;
+}
+
 template <typename T, int MT, int NT>
 void launch_halo(hipStream_t st, const T* W, const T* X, int K, int C, int taps, int dil, const ConvEpi& e, size_t lds) {
     const long RT = 16 * MT;
@@ -195,7 +344,7 @@ bool try_halo(hipStream_t st, const T* W, const T* X, int K, int C, int taps, in
 }  // namespace
 
 // Returns false when the shape does not fit the LDS-tile kernel (the caller then uses the tap-addressed GEMM).
-// X rows must be contiguous (row stride == channels per tap) and readable for 128 rows + the halo past e.M.
+// X rows must be contiguous (row stride == channels per tap) and readable for 256 rows + the halo past e.M.
 bool launch_conv_halo(hipStream_t st, int dtype, const void* W, const void* X, int K, int ldx, int taps, long tap_stride, const ConvEpi& e) {
     if (taps < 1 || K % taps != 0) return false;
     const int C = K / taps;
@@ -204,7 +353,11 @@ bool launch_conv_halo(hipStream_t st, int dtype, const void* W, const void* X, i
     if (taps > 1 && (tap_stride <= 0 || tap_stride % ldx != 0)) return false;
     const long dil = taps > 1 ? tap_stride / ldx : 1;
     if (dil < 1 || dil > 64) return false;
-    if (dtype == BF16) return try_halo<bf16_t>(st, (const bf16_t*)W, (const bf16_t*)X, K, C, taps, (int)dil, e);
+    if (dtype == BF16) {
+        if (try_tile<bf16_t>(st, (const bf16_t*)W, (const bf16_t*)X, K, C, taps, (int)dil, e)) return true;
+        return try_halo<bf16_t>(st, (const bf16_t*)W, (const bf16_t*)X, K, C, taps, (int)dil, e);
+    }
+    if (try_tile<float>(st, (const float*)W, (const float*)X, K, C, taps, (int)dil, e)) return true;
     return try_halo<float>(st, (const float*)W, (const float*)X, K, C, taps, (int)dil, e);
 }
 

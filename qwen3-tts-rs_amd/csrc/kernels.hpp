@@ -196,7 +196,7 @@ void launch_gemm_rows_epi(hipStream_t st, int dtype, const void* W, const void* 
                           const ConvEpi& e);
 // k_conv.hip: same contract with the input tile held in LDS; false = shape not covered (use launch_gemm_rows_epi).
 // X must be readable for CONV_HALO_SLACK rows past e.M.
-constexpr long CONV_HALO_SLACK = 256;
+constexpr long CONV_HALO_SLACK = 384;
 bool launch_conv_halo(hipStream_t st, int dtype, const void* W, const void* X, int K, int ldx, int taps, long tap_stride, const ConvEpi& e);
 void launch_rvq_gather(hipStream_t st, int dtype, const float* table, const unsigned* codes, const int* rows, const int* starts,
                        const int* lens, int U, int Tc, int Q, int csize, int Dc, int T_max, long S, int P, void* out, int ld);
