@@ -38,21 +38,54 @@ __device__ __forceinline__ void ld4(const float* p, float (&o)[4]) {
 
 // One float4 of GEMM output: row m of the GEMM row space (strip u = m / S_in, step tp = m % S_in), columns n .. n + 3
 // (n is a multiple of 4, so are Cout and every channel offset: all parameter vectors are read as float4).
+// The tail is split in three so that a kernel can hoist what depends on the columns only (conv_epi_cols), issue the
+// residual loads of several rows before it needs any of them (conv_epi_resid), and then do the arithmetic and the
+// stores (conv_epi_finish); conv_epi_apply is the three in a row.
+struct EpiCols {
+    int j, co;
+    float bias[4], scale[4], al[4], den[4];
+};
+
 template <typename T>
-__device__ __forceinline__ void conv_epi_apply(const ConvEpi& e, long u, int tp, int n, float (&v)[4]) {
-    int j = 0, co = n;
-    if (e.r != 1) { j = n / e.Cout; co = n - j * e.Cout; }
-    const long orow = u * e.S_out + e.P_out + (long)tp * e.r + j;
-    const long o_off = orow * e.ld_out + co;
-    if (e.bias) {
-        float b[4];
-        ld4(e.bias + co, b);
+__device__ __forceinline__ void conv_epi_cols(const ConvEpi& e, int n, EpiCols& c) {
+    c.j = 0;
+    c.co = n;
+    if (e.r != 1) { c.j = n / e.Cout; c.co = n - c.j * e.Cout; }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += b[q];
+    for (int q = 0; q < 4; ++q) { c.bias[q] = 0.f; c.scale[q] = 1.f; c.al[q] = 0.f; c.den[q] = 1.f; }
+    if (e.bias) ld4(e.bias + c.co, c.bias);
+    if (e.scale) ld4(e.scale + c.co, c.scale);
+    if (e.out2 && e.act2 != 1) {
+        ld4(e.alpha_exp + c.co, c.al);
+        ld4(e.beta_den + c.co, c.den);
+    }
+}
+
+__device__ __forceinline__ long conv_epi_offset(const ConvEpi& e, const EpiCols& c, long u, int tp) {
+    const long orow = u * e.S_out + e.P_out + (long)tp * e.r + c.j;
+    return orow * e.ld_out + c.co;
+}
+
+template <typename T>
+__device__ __forceinline__ void conv_epi_resid(const ConvEpi& e, long o_off, float (&rr)[4]) {
+    if (e.resid) {
+        const T* rp = (const T*)e.resid + o_off;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rr[q] = to_f32<T>(rp[q]);
+    } else if (e.resid_f32) {
+        ld4(e.resid_f32 + o_off, rr);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void conv_epi_finish(const ConvEpi& e, const EpiCols& c, long u, long o_off, float (&v)[4], const float (&rr)[4]) {
+    if (e.bias) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += c.bias[q];
     }
     if (e.bias_u) {
         float b[4];
-        ld4(e.bias_u + u * e.Cout + co, b);
+        ld4(e.bias_u + u * e.Cout + c.co, b);
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] += b[q];
     }
@@ -70,23 +103,14 @@ __device__ __forceinline__ void conv_epi_apply(const ConvEpi& e, long u, int tp,
         }
     }
     if (e.scale) {
-        float sc[4];
-        ld4(e.scale + co, sc);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = v[q] * sc[q];
+        for (int q = 0; q < 4; ++q) v[q] = v[q] * c.scale[q];
     }
-    if (e.resid) {
-        const T* rp = (const T*)e.resid + o_off;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = to_f32<T>(rp[q]) + v[q];
-    }
-    if (e.resid_f32) {
-        float rr[4];
-        ld4(e.resid_f32 + o_off, rr);
+    if (e.resid || e.resid_f32) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = rr[q] + v[q];
     }
-    if (e.Cvalid && co >= e.Cvalid) return;  // columns past the layer's real width are padding
+    if (e.Cvalid && c.co >= e.Cvalid) return;  // columns past the layer's real width are padding
     if (e.out) {
         T* o = (T*)e.out + o_off;
 #pragma unroll
@@ -101,18 +125,25 @@ __device__ __forceinline__ void conv_epi_apply(const ConvEpi& e, long u, int tp,
             o[q] = from_f32<T>(x > 0.f ? x : expf(x) - 1.0f);
         }
     } else if (e.out2) {
-        float al[4], den[4];
-        ld4(e.alpha_exp + co, al);
-        ld4(e.beta_den + co, den);
         T* o = (T*)e.out2 + o_off;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             // SnakeBeta in f32 on the value the next op would read: the stored (rounded) one unless the stream is kept in f32
             const float x = (e.out_f32 || e.resid_f32) ? v[q] : to_f32<T>(from_f32<T>(v[q]));
-            const float sn = snake_sin<T>(x * al[q]);
-            o[q] = from_f32<T>(x + snake_div<T>(sn * sn, den[q]));
+            const float sn = snake_sin<T>(x * c.al[q]);
+            o[q] = from_f32<T>(x + snake_div<T>(sn * sn, c.den[q]));
         }
     }
+}
+
+template <typename T>
+__device__ __forceinline__ void conv_epi_apply(const ConvEpi& e, long u, int tp, int n, float (&v)[4]) {
+    EpiCols c;
+    conv_epi_cols<T>(e, n, c);
+    const long o_off = conv_epi_offset(e, c, u, tp);
+    float rr[4] = {0.f, 0.f, 0.f, 0.f};
+    conv_epi_resid<T>(e, o_off, rr);
+    conv_epi_finish<T>(e, c, u, o_off, v, rr);
 }
 
 }  // namespace qtts

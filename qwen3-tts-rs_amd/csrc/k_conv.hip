@@ -48,6 +48,64 @@ struct CFrag<float> {
     }
 };
 
+// Input tile -> LDS by DMA (no registers, every load of the tile in flight at once).  A wave instruction fills 64
+// consecutive 16-byte slots, so the XOR swizzle is applied on the source side: slot (row, pcol) takes column pcol ^ (row & 7).
+// The last instruction may run up to 63 slots past `total`: the tile allocation is rounded up to 1 KiB and the rows it
+// reads lie inside the slack every caller keeps readable behind the activations.
+template <typename T>
+__device__ __forceinline__ void tile_load_dma(uint4* tile, const T* src, int C, int vpr, int total) {
+    constexpr int VPE = 16 / (int)sizeof(T);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nblk = (total + 63) >> 6;
+    for (int k = wave; k < nblk; k += 4) {
+        const int L = k * 64 + lane;
+        const int row = L / vpr, pcol = L - row * vpr;
+        const T* p = src + (long)row * C + (pcol ^ (row & 7)) * VPE;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                         (__attribute__((address_space(3))) void*)(tile + k * 64), 16, 0, 0);
+    }
+}
+
+// One epilogue pass over the transposed accumulators in LDS: RT rows x 4 * GPR columns starting at column n0.  A thread keeps
+// the same four columns for every row it visits, so the column parameters are loaded once, and the residual loads of
+// up to eight rows are issued before the first of them is needed.
+template <typename T, int RT, int GPR, int OP>
+__device__ __forceinline__ void epi_pass(const ConvEpi& e, const float* otile, const int* row_u, const int* row_tp, int n0) {
+    static_assert(256 % GPR == 0 && RT % (256 / GPR) == 0, "epilogue pass geometry");
+    constexpr int RPI = 256 / GPR, IT = RT / RPI;
+    // f32 runs call the full-precision sine: unrolling eight of those tails spills, and their speed is not the point
+    constexpr int U = sizeof(T) == 4 ? 1 : (IT >= 8 ? 8 : IT);
+    static_assert(IT % U == 0, "epilogue pass geometry");
+    const int c4 = threadIdx.x % GPR, r0 = threadIdx.x / GPR;
+    EpiCols pc;
+    conv_epi_cols<T>(e, n0 + 4 * c4, pc);
+    for (int it0 = 0; it0 < IT; it0 += U) {
+        float rr[U][4];
+        long off[U];
+        int tp[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int row = (it0 + k) * RPI + r0;
+            tp[k] = row_tp[row];
+            off[k] = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rr[k][q] = 0.f;
+            if (tp[k] >= 0) {
+                off[k] = conv_epi_offset(e, pc, row_u[row], tp[k]);
+                conv_epi_resid<T>(e, off[k], rr[k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            if (tp[k] < 0) continue;
+            const int row = (it0 + k) * RPI + r0;
+            const float4 a4 = *reinterpret_cast<const float4*>(otile + row * OP + 4 * c4);
+            float v[4] = {a4.x, a4.y, a4.z, a4.w};
+            conv_epi_finish<T>(e, pc, row_u[row], off[k], v, rr[k]);
+        }
+    }
+}
+
 template <typename T, int MT, int NT>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W, const T* __restrict__ X, int K, int C, int taps, int dil,
                                                         ConvEpi e) {
@@ -60,13 +118,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
     const long m0 = (long)blockIdx.y * RT;
     const int vpr = C / VPE;  // vectors per row (a multiple of 8)
     const int rows_t = RT + (taps - 1) * dil;
-    {
-        const T* src = X + m0 * C;
-        for (int v = threadIdx.x; v < rows_t * vpr; v += 256) {
-            const int row = v / vpr, col = v - row * vpr;
-            tile[row * vpr + (col ^ (row & 7))] = *reinterpret_cast<const uint4*>(src + (long)row * C + col * VPE);
-        }
-    }
+    tile_load_dma<T>(tile, X + m0 * C, C, vpr, rows_t * vpr);
     // wave w owns the 16-column tiles 4 j + w of the block's 64 NT columns (interleaved, so that an epilogue pass over
     // tiles j .. j + PT - 1 of every wave covers one contiguous run of columns)
     const int nb = blockIdx.x * (64 * NT);
@@ -87,6 +139,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
 #pragma unroll
             for (int j = 0; j < NT; ++j) a[s][j].load(wrow[j] + (size_t)s * F::CHUNK);
         }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's part of the tile has landed before it signals the barrier
     __syncthreads();
     for (int q0 = 0; q0 < nC; q0 += PF) {
 #pragma unroll
@@ -142,16 +195,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
             for (int jj = 0; jj < PT; ++jj)
                 *reinterpret_cast<f32x4_t*>(otile + (16 * i + r) * OP + (4 * jj + wave) * 16 + 4 * g) = acc[i][p * PT + jj];
         __syncthreads();
-        constexpr int GPR = CP / 4;
-        for (int idx = threadIdx.x; idx < RT * GPR; idx += 256) {
-            const int row = idx / GPR, c4 = idx - row * GPR;
-            const int tp = row_tp[row];
-            if (tp < 0) continue;
-            const long u = row_u[row];
-            const float4 a4 = *reinterpret_cast<const float4*>(otile + row * OP + 4 * c4);
-            float v[4] = {a4.x, a4.y, a4.z, a4.w};
-            conv_epi_apply<T>(e, u, tp, nb + p * CP + 4 * c4, v);
-        }
+        epi_pass<T, RT, CP / 4, OP>(e, otile, row_u, row_tp, nb + p * CP);
     }
 }
 
@@ -205,11 +249,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const T* __restrict__ W,
             const int ph = q / per_phase, rem = q - ph * per_phase;
             if (rem == 0) {  // new phase: its channels of the input tile
                 __syncthreads();
-                const T* src = X + m0 * C + (size_t)ph * cph;
-                for (int v = threadIdx.x; v < rows_t * vpr; v += 256) {
-                    const int row = v / vpr, col = v - row * vpr;
-                    tile[row * vpr + (col ^ (row & 7))] = *reinterpret_cast<const uint4*>(src + (long)row * C + col * VPE);
-                }
+                tile_load_dma<T>(tile, X + m0 * C + (size_t)ph * cph, C, vpr, rows_t * vpr);
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
                 __syncthreads();
             }
             if (q + 1 < nC) {
@@ -258,16 +299,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const T* __restrict__ W,
             for (int jj = 0; jj < PT; ++jj)
                 *reinterpret_cast<f32x4_t*>(otile + (wm * (16 * MT) + 16 * i + r) * OP + (jj * WN + wn) * 16 + 4 * g) = acc[i][p * PT + jj];
         __syncthreads();
-        constexpr int GPR = CP / 4;
-        for (int idx = threadIdx.x; idx < RT * GPR; idx += 256) {
-            const int row = idx / GPR, c4 = idx - row * GPR;
-            const int tp = row_tp[row];
-            if (tp < 0) continue;
-            const long u = row_u[row];
-            const float4 a4 = *reinterpret_cast<const float4*>(otile + row * OP + 4 * c4);
-            float v[4] = {a4.x, a4.y, a4.z, a4.w};
-            conv_epi_apply<T>(e, u, tp, nb + p * CP + 4 * c4, v);
-        }
+        epi_pass<T, RT, CP / 4, OP>(e, otile, row_u, row_tp, nb + p * CP);
     }
 }
 
@@ -275,7 +307,7 @@ template <typename T, int MT, int NT, int WN>
 void launch_tile(hipStream_t st, const T* W, const T* X, int K, int C, int taps, int dil, int cph, const ConvEpi& e) {
     constexpr int RT = 16 * MT * (4 / WN);
     constexpr int PT = NT % 2 == 0 ? 2 : 1;
-    const size_t lds = std::max((size_t)(RT + (taps - 1) * dil) * cph * sizeof(T), (size_t)RT * (16 * WN * PT + 4) * 4);
+    const size_t lds = (std::max((size_t)(RT + (taps - 1) * dil) * cph * sizeof(T), (size_t)RT * (16 * WN * PT + 4) * 4) + 1023) / 1024 * 1024;
     const long gy = (e.M + RT - 1) / RT;
     auto* fn = conv_tile_kernel<T, MT, NT, WN>;
     QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -291,8 +323,13 @@ bool try_tile(hipStream_t st, const T* W, const T* X, int K, int C, int taps, in
     static const long min_k = getenv("QTTS_CONV_TILE2_K") ? atol(getenv("QTTS_CONV_TILE2_K")) : 5000;
     const long halo = (long)(taps - 1) * dil;
     // one block per CU (348 registers per lane): nothing hides its tile load and its epilogue, so it only wins where the K walk
-    // is long (measured on the vocoder: 7-tap convs over >= 768 channels 27 % faster, everything narrower slower)
-    if (off || e.M < min_rows || halo > 128 || (e.M + 255) / 256 > 0x7fffffffL || (long)taps * C < min_k) return false;
+    // is long
+    // (measured on the vocoder: wins for 7-tap convs over >= 768 channels, for the wide two-tap transposed convs, and where the
+    // halo of a dilated conv would push the other kernel's tile past 64 KB; loses on everything narrower)
+    const bool long_k = (long)taps * C >= min_k;
+    const bool wide_ct = taps == 2 && (long)taps * C >= 1536 && e.N >= 1920;
+    const bool big_halo = (size_t)(64 + halo) * C * sizeof(T) > (size_t)64 * 1024;
+    if (off || e.M < min_rows || halo > 128 || (e.M + 255) / 256 > 0x7fffffffL || !(long_k || wide_ct || big_halo)) return false;
     // channels per phase: as many as keep the tile of 256 rows + halo within 96 KB
     int cph = 0;
     for (int c = C; c >= 64; c -= 64)
@@ -331,7 +368,7 @@ bool try_halo(hipStream_t st, const T* W, const T* X, int K, int C, int taps, in
     else if (fits64) { mt = 4; nt = 1; }
     else return false;
     const int rows = 16 * mt;
-    const size_t lds = std::max((rows + halo) * row_bytes, mt == 8 ? otile128 : otile64);
+    const size_t lds = (std::max((rows + halo) * row_bytes, mt == 8 ? otile128 : otile64) + 1023) / 1024 * 1024;
     if ((e.M + rows - 1) / rows > 0x7fffffffL) return false;
     if (mt == 4 && nt == 4) launch_halo<T, 4, 4>(st, W, X, K, C, taps, dil, e, lds);
     else if (mt == 8 && nt == 2) launch_halo<T, 8, 2>(st, W, X, K, C, taps, dil, e, lds);
