@@ -59,14 +59,23 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(const float* __restrict
     const long row = blockIdx.x;
     float ss = 0.f;
     if (H <= RMAX * 1024) {
-        float4 keep[RMAX];
+        // every load of the row (slabs, residual, norm weight) is issued before the first store: resid_out may alias
+        // resid, and a store in between would serialise the memory round trips
+        float4 keep[RMAX], gw[RMAX];
 #pragma unroll
         for (int it = 0; it < RMAX; ++it) {
             const int i = threadIdx.x * 4 + it * 1024;
             if (i < H) {
-                const float4 s = resid_combine(resid, part, KS, ks_stride, bias, scale, row * H + i, i);
+                keep[it] = resid_combine(resid, part, KS, ks_stride, bias, scale, row * H + i, i);
+                if (norm_w) gw[it] = *reinterpret_cast<const float4*>(norm_w + i);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < RMAX; ++it) {
+            const int i = threadIdx.x * 4 + it * 1024;
+            if (i < H) {
+                const float4 s = keep[it];
                 *reinterpret_cast<float4*>(resid_out + row * H + i) = s;
-                keep[it] = s;
                 ss += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
             }
         }
@@ -78,7 +87,7 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(const float* __restrict
             const int i = threadIdx.x * 4 + it * 1024;
             if (i < H) {
                 const float4 x = keep[it];
-                const float4 g = *reinterpret_cast<const float4*>(norm_w + i);
+                const float4 g = gw[it];
                 const float4 y = make_float4(x.x / m * g.x, x.y / m * g.y, x.z / m * g.z, x.w / m * g.w);
                 if (xn_f32) *reinterpret_cast<float4*>(xn_f32 + row * H + i) = y;
                 T* o = xn + row * H + i;

@@ -197,6 +197,39 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
                 __syncthreads();
             }
             // ---- softmax over the kept candidates, then the renormalised inverse-CDF draw
+            if (n <= 64) {
+                // Common case (top-k <= 64): one candidate per lane of wave 0.  The reference's sequential f32 sums are walked
+                // in index order with lane reads instead of LDS round trips; the arithmetic is the same, value for value.
+                if (tid < 64) {
+                    const bool in = tid < n;
+                    const float x = in ? sv[tid] : -INFINITY;
+                    const float mx = wave_max(x);
+                    const float ex = in ? expf(x - mx) : 0.f;
+                    float sum = 0.f;
+                    for (int i = 0; i < n; ++i) sum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ex), i));
+                    const float pr = in ? ex / sum : 0.f;
+                    float total = 0.f;
+                    for (int i = 0; i < n; ++i) total += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pr), i));
+                    // Iterator::max_by keeps the LAST of equal maxima (fallbacks at sampling.rs:370-375, 391-396)
+                    const float pmax = wave_max(in ? pr : -INFINITY);
+                    const unsigned long long eq = __ballot(in && pr == pmax);
+                    const int best = eq ? 63 - __builtin_clzll(eq) : 0;
+                    int pick = -1;
+                    if (total > 0.0f && isfinite(total)) {
+                        const float u = a.uniforms[((long)b * (a.row_stride / a.G) + step) * a.G + a.g];
+                        const float inv = 1.0f / total;
+                        float cum = 0.f;
+                        for (int i = 0; i < n; ++i) {
+                            cum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pr), i)) * inv;
+                            if (u < cum) { pick = i; break; }
+                        }
+                    }
+                    if (pick < 0) pick = best;
+                    if (tid == 0) sh_tok = si[pick];
+                }
+                __syncthreads();
+                token = sh_tok;
+            } else {
             {
                 float mloc = -INFINITY;
                 for (int i = tid; i < n; i += 256) mloc = fmaxf(mloc, sv[i]);
@@ -240,6 +273,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
             }
             __syncthreads();
             token = sh_tok;
+            }
         }
     }
     // the sampled code's embedding row is the next code-predictor pass's input: copy it here instead of in a kernel of its own
