@@ -150,7 +150,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    stats = dict(prefill_ms=0.0, frames_ms=0.0, frames=0, codec_ms=0.0, audio_s=0.0, step_ms=[], first_ms=[])
+    stats = dict(prefill_ms=0.0, frames_ms=0.0, frames=0, codec_ms=0.0, audio_s=0.0, step_ms=[], first_ms=[], launch_host_ms=0.0)
     out_last = [None]
     lock = threading.Lock()
 
@@ -172,6 +172,7 @@ def main():
                 stats["prefill_ms"] += mod.last_timing["prefill_ms"]
                 stats["frames_ms"] += mod.last_timing["frames_ms"]
                 stats["frames"] += mod.last_timing["frames"]
+                stats["launch_host_ms"] += mod.last_timing["graph_launch_host_ms"]
                 stats["codec_ms"] += 0.0 if args.no_codec else mod.codec_device_ms()
                 stats["audio_s"] += sum(out.effective_lengths) * FRAME_SECONDS
                 stats["step_ms"].append((time.perf_counter() - t_s) * 1e3)
@@ -271,6 +272,7 @@ def main():
             "phase_ms_per_step": {"prefill": round(stats["prefill_ms"] / args.steps, 2), "frames": round(stats["frames_ms"] / args.steps, 2),
                                   "codec_device": round(stats["codec_ms"] / args.steps, 2)},
             "ms_per_frame": round(ms_per_frame, 4),
+            "graph_launch_host_ms_per_frame": round(stats["launch_host_ms"] / frames_run, 4),
             "roofline": roofline, "roofline_gemm": gemm, "roofline_codec": codec, "cpu_baseline": cpu,
         }
     for mod in models:

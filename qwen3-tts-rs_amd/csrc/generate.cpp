@@ -594,11 +594,14 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         dbg->chunk_cb(dbg->chunk_user, hc.data(), B, frames);
     };
     bool done = false;
+    double launch_host_ms = 0;  // host time inside hipGraphLaunch (the runtime enqueues the graph's nodes one by one)
     while (steps_done < max_new && !done) {
         if (!chunk_sent && steps_done >= dbg->first_frames) send_chunk(dbg->first_frames);
         if (steps_done % EOS_POLL == 0 && all_eos()) { done = true; break; }
         if (g.graph_exec && use_graph && !tracing) {
+            const auto t0 = std::chrono::steady_clock::now();
             QTTS_HIP(hipGraphLaunch(g.graph_exec, st));
+            launch_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         } else {
             talker_step();
             if (tracing) trace_copy(steps_done);
@@ -638,6 +641,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     m.timing[3] = (double)(g.timer.used / 2);
     m.timing[4] = g.timer.bytes;
     m.timing[5] = (double)steps_done;
+    m.timing[7] = launch_host_ms;
     m.gemm_profile = g.timer.by_shape();
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);

@@ -317,7 +317,7 @@ class Model:
         tm = (C.c_double * 8)()
         check(self.lib.qtts_last_timing(self._m, tm, 8))
         self.last_timing = dict(prefill_ms=tm[0], frames_ms=tm[1], gemm_ms=tm[2], gemm_launches=int(tm[3]),
-                                gemm_bytes=tm[4], frames=int(tm[5]))
+                                gemm_bytes=tm[4], frames=int(tm[5]), graph_launch_host_ms=tm[7])
         steps = outs[0].num_steps
         out = Output(codes=codes[:, :steps].copy(), num_steps=steps, effective_lengths=[outs[i].effective_len for i in range(n)])
         if trace:
