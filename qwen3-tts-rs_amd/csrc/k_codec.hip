@@ -121,11 +121,33 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const T* __restrict__ x
     const int vpr = row_bytes / 16;
     float* wl = reinterpret_cast<float*>(smem + 70 * pitch);
     const unsigned char* src = reinterpret_cast<const unsigned char*>(x + ((long)u * S + P + t0 - 6) * C);
-    for (int v = threadIdx.x; v < 70 * vpr; v += 256) {
-        const int row = v / vpr, c16 = v % vpr;
-        *reinterpret_cast<uint4*>(smem + row * pitch + c16 * 16) = *reinterpret_cast<const uint4*>(src + (long)row * row_bytes + c16 * 16);
+    // four loads in flight per thread before the first LDS store (a load-store-load chain would pay the memory latency per vector)
+    for (int base = 0; base < 70 * vpr; base += 1024) {
+        uint4 buf[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = base + k * 256 + (int)threadIdx.x;
+            if (v < 70 * vpr) buf[k] = *reinterpret_cast<const uint4*>(src + (long)(v / vpr) * row_bytes + (v % vpr) * 16);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = base + k * 256 + (int)threadIdx.x;
+            if (v < 70 * vpr) *reinterpret_cast<uint4*>(smem + (v / vpr) * pitch + (v % vpr) * 16) = buf[k];
+        }
     }
-    for (int i = threadIdx.x; i < 7 * C; i += 256) wl[i] = w[i];
+    for (int base = 0; base < 7 * C; base += 1024) {
+        float wb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + k * 256 + (int)threadIdx.x;
+            if (i < 7 * C) wb[k] = w[i];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = base + k * 256 + (int)threadIdx.x;
+            if (i < 7 * C) wl[i] = wb[k];
+        }
+    }
     __syncthreads();
     const int sidx = threadIdx.x >> 2, part = threadIdx.x & 3;
     const int cq = C / 4, c0 = part * cq;
