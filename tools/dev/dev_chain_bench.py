@@ -1,6 +1,6 @@
 """Developer scratch: cost of a dependent kernel boundary with plain vs write-through producer stores."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from qwen3_tts_rs_amd import _lib
 lib = _lib.load()
 lib.qtts_bench_sync.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]

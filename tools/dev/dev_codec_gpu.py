@@ -1,7 +1,7 @@
 """Developer scratch (not collected by pytest): codec decoder on the GPU against the oracle."""
 import sys, time, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import bind
 from qwen3_tts_rs_amd import synth, synthetic_model, round_bf16
 

@@ -1,7 +1,7 @@
 """Developer scratch: codec decoder at benchmark size (64 utterances x 375 frames)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from qwen3_tts_rs_amd import Model, LoaderConfig, synth
 cfg, ccfg, tmpl = synth.shape_set("S17")

@@ -1,7 +1,7 @@
 """Developer scratch (not collected by pytest): frame-time probe on a large shape set."""
 import sys, time, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from qwen3_tts_rs_amd import synth, Model, LoaderConfig, GenerationRequest, SamplingConfig
 

@@ -1,6 +1,6 @@
 """Developer scratch: one S17 B=64 run for rocprofv3."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from qwen3_tts_rs_amd import synth, Model, LoaderConfig, GenerationRequest, SamplingConfig
 shape = sys.argv[1] if len(sys.argv) > 1 else "S17"

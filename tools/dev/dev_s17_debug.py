@@ -1,7 +1,7 @@
 """Developer scratch: sanity of the 1.7B-like shape set at several batch sizes."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from qwen3_tts_rs_amd import Model, LoaderConfig, synth, GenerationRequest, SamplingConfig
 cfg, ccfg, tmpl = synth.shape_set(os.environ.get("SHAPE", "S17"))

@@ -1,5 +1,5 @@
 import sys, os, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from qwen3_tts_rs_amd import _lib
 lib = _lib.load()
 ctx = C.c_void_p()

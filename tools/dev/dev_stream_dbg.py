@@ -1,8 +1,8 @@
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from qwen3_tts_rs_amd import synthetic_model
-g = np.load(os.path.join(os.path.dirname(__file__), "golden", "t0_golden.npz"))["codec_codes"]
+g = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden", "t0_golden.npz"))["codec_codes"]
 m, cfg, ccfg, tmpl = synthetic_model("T0", dtype="f32", codec=True, talker=False)
 codes = np.stack([g[:300], g[300:600]])
 whole = m.decode_codes(codes)
