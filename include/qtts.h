@@ -174,6 +174,9 @@ int qtts_mel(qtts_model* m, const float* audio, const int* n_samples, int B, int
              int frames_stride, int* n_frames);
 /* ConditionalGeneration::encode_speaker (nn/generation.rs:140) on top of qtts_mel: emb_out [B][enc_dim]. */
 int qtts_speaker_embed(qtts_model* m, const float* audio, const int* n_samples, int B, int max_samples, float* emb_out);
+/* The same on a mel the caller already holds - Model::create_voice_clone_prompt_from_mel (model/mod.rs:579-612):
+ * mel [B][frames_stride][128] f32 log-mel (frames x mels, the layout qtts_mel writes), n_frames[b] valid frames. */
+int qtts_speaker_embed_mel(qtts_model* m, const float* mel, const int* n_frames, int B, int frames_stride, float* emb_out);
 
 /* Shape queries a binding needs to size its buffers. */
 int qtts_model_info(qtts_model* m, int* hidden, int* vocab, int* groups, int* total_upsample, int* enc_dim);

@@ -49,7 +49,7 @@ EXPORTS = ["qtts_init", "qtts_shutdown", "qtts_last_error", "qtts_stream", "qtts
            "qtts_model_load_tensor_device", "qtts_model_finalize", "qtts_model_free", "qtts_generate", "qtts_generate_ex",
            "qtts_last_timing", "qtts_codec_decode", "qtts_mel", "qtts_speaker_embed", "qtts_model_info",
            "qtts_gemm_profile", "qtts_bench_gemm", "qtts_bench_stream", "qtts_encode_audio",
-           "qtts_codec_stream_open", "qtts_codec_stream_push", "qtts_codec_stream_close"]
+           "qtts_speaker_embed_mel", "qtts_codec_stream_open", "qtts_codec_stream_push", "qtts_codec_stream_close"]
 
 _lib = None
 
@@ -81,6 +81,7 @@ def load():
                                       C.c_int64, C.c_void_p]
     lib.qtts_mel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.qtts_speaker_embed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.qtts_speaker_embed_mel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.qtts_encode_audio.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.qtts_codec_stream_open.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     lib.qtts_codec_stream_push.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]

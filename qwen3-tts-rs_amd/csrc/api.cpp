@@ -185,6 +185,13 @@ int qtts_speaker_embed(qtts_model* m, const float* audio, const int* n_samples, 
     QTTS_API_END
 }
 
+int qtts_speaker_embed_mel(qtts_model* m, const float* mel, const int* n_frames, int B, int frames_stride, float* emb_out) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(m && mel && n_frames && emb_out, ERR_BAD_ARG, "qtts_speaker_embed_mel: null argument");
+    run_speaker_embed_mel(m->m, mel, n_frames, B, frames_stride, emb_out);
+    QTTS_API_END
+}
+
 // Diagnostics: average duration (microseconds, HIP events) of `iters` back-to-back launches of the weight-streaming
 // GEMM on random-free zero... buffers of the given shape; used by the benchmark to report the kernel's roofline.
 int qtts_bench_gemm(qtts_ctx* ctx, int dtype, int M, int N, int K, int KS, int iters, double* avg_us) {

@@ -25,5 +25,6 @@ void finalize_speaker(Model& m);
 void run_mel(Model& m, const float* audio, const int* n_samples, int B, int max_samples, float* mel_out, int frames_stride,
              int* n_frames);
 void run_speaker_embed(Model& m, const float* audio, const int* n_samples, int B, int max_samples, float* emb_out);
+void run_speaker_embed_mel(Model& m, const float* mel, const int* n_frames, int B, int frames_stride, float* emb_out);
 
 }  // namespace qtts

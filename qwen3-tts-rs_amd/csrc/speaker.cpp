@@ -6,6 +6,7 @@
 // are small per-(utterance, channel) kernels (k_speaker.hip).
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 #include "generate.hpp"
 #include "prep.hpp"
@@ -210,7 +211,26 @@ void run_mel(Model& m, const float* audio, const int* n_samples, int B, int max_
     for (int u = 0; u < B; ++u) n_frames[u] = b.frames[(size_t)u];
 }
 
+namespace {
+void speaker_embed_impl(Model& m, const float* audio, const int* n_samples, int max_samples, const float* mel_in, const int* n_frames,
+                        int frames_stride, int B, float* emb_out);
+}
+
 void run_speaker_embed(Model& m, const float* audio, const int* n_samples, int B, int max_samples, float* emb_out) {
+    speaker_embed_impl(m, audio, n_samples, max_samples, nullptr, nullptr, 0, B, emb_out);
+}
+
+// ConditionalGeneration::encode_speaker on a mel the caller already holds (Model::create_voice_clone_prompt_from_mel,
+// model/mod.rs:579-612): mel_in [B][frames_stride][128] f32 (log-mel, frames x mels), n_frames[b] valid frames.
+void run_speaker_embed_mel(Model& m, const float* mel_in, const int* n_frames, int B, int frames_stride, float* emb_out) {
+    QTTS_CHECK(B >= 1 && frames_stride >= 1, ERR_BAD_ARG, "speaker encoder: bad mel batch shape");
+    for (int u = 0; u < B; ++u) QTTS_CHECK(n_frames[u] >= 1 && n_frames[u] <= frames_stride, ERR_BAD_ARG, "speaker encoder: n_frames out of range");
+    speaker_embed_impl(m, nullptr, nullptr, 0, mel_in, n_frames, frames_stride, B, emb_out);
+}
+
+namespace {
+void speaker_embed_impl(Model& m, const float* audio, const int* n_samples, int max_samples, const float* mel_in, const int* n_frames,
+                        int frames_stride, int B, float* emb_out) {
     QTTS_CHECK(m.finalized && m.spk_state, ERR_STATE, "model is not finalized");
     SpeakerState& s = *m.spk_state;
     QTTS_CHECK(s.have_encoder, ERR_STATE,
@@ -219,7 +239,16 @@ void run_speaker_embed(Model& m, const float* audio, const int* n_samples, int B
     hipStream_t st = m.ctx->stream;
     const int dt = m.dtype;
     const size_t es = dtype_size(dt);
-    const Batch b = stage_audio(m, s, audio, n_samples, B, max_samples);
+    Batch b;
+    if (mel_in) {
+        b.B = B;
+        b.frames.assign(n_frames, n_frames + B);
+        for (int f : b.frames) b.max_frames = std::max(b.max_frames, f);
+        s.lens.ensure((size_t)B * 4);
+        QTTS_HIP(hipMemcpy(s.lens.p, b.frames.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+    } else {
+        b = stage_audio(m, s, audio, n_samples, B, max_samples);
+    }
     const int Tm = b.max_frames, P = s.P, U = B;
     for (int u = 0; u < U; ++u)
         QTTS_CHECK(b.frames[(size_t)u] > s.P, ERR_BAD_ARG, "speaker encoder: clip too short for the reflect padding of its convolutions");
@@ -256,9 +285,18 @@ void run_speaker_embed(Model& m, const float* audio, const int* n_samples, int B
     auto at = [&](const DevBuf& d, long row, int ld) { return (const char*)d.p + (size_t)row * ld * es; };
 
     // mel -> strips (model dtype, like the reference's cast before the encoder) with reflected borders
-    zero(s.melT, NMEL);
-    launch_mel(st, dt, s.audio.as<float>(), s.nsamp.as<int>(), U, max_samples, Tm, s.window.as<float>(), s.twiddle.as<float>(),
-               s.fbT.as<float>(), nullptr, 0, s.melT.p, S, P);
+    if (mel_in) {
+        // the caller's mel, cast to the model dtype and laid out as strips with P leading rows
+        std::vector<float> strips(rows * NMEL, 0.f);
+        for (int u = 0; u < U; ++u)
+            std::memcpy(&strips[((size_t)u * S + P) * NMEL], mel_in + (size_t)u * frames_stride * NMEL, (size_t)b.frames[(size_t)u] * NMEL * 4);
+        QTTS_HIP(hipStreamSynchronize(st));
+        upload(s.melT, strips, dt);
+    } else {
+        zero(s.melT, NMEL);
+        launch_mel(st, dt, s.audio.as<float>(), s.nsamp.as<int>(), U, max_samples, Tm, s.window.as<float>(), s.twiddle.as<float>(),
+                   s.fbT.as<float>(), nullptr, 0, s.melT.p, S, P);
+    }
     if (s.pad0 > 0) launch_reflect_fill(st, dt, s.melT.p, d_len, U, S, P, s.pad0, NMEL);
     // blocks.0: TDNN k = 5 + ReLU
     zero(s.h0, s.block0.CoutP);
@@ -314,5 +352,6 @@ void run_speaker_embed(Model& m, const float* audio, const int* n_samples, int B
     QTTS_HIP(hipMemcpyAsync(emb_out, s.emb.p, (size_t)U * s.enc_dim * 4, hipMemcpyDeviceToHost, st));
     QTTS_HIP(hipStreamSynchronize(st));
 }
+}  // namespace
 
 }  // namespace qtts

@@ -144,6 +144,7 @@ class VoiceClonePromptItem:  # model/voice_clone.rs:64-181 (the transcript arriv
 class LoaderConfig:  # model/loader.rs:31-54
     dtype: str = "bf16"
     load_tokenizer: bool = True
+    load_text_tokenizer: bool = True
     device: int = 0
     load_encoder: bool = True   # codec encoder tensors (`encoder.*`): needed only for encode_audio / ICL voice clone
 
@@ -165,6 +166,7 @@ class Model:
         check(self.lib.qtts_model_create(self._ctx, json.dumps(config).encode(), cj, self.dtype, C.byref(self._m)))
         self._finalized = False
         self.last_timing = None
+        self.text_processor = None  # text.TextProcessor; set by ModelLoader when the directory holds tokenizer.json
 
     def close(self):
         if getattr(self, "_m", None) is not None and self._m:
@@ -491,6 +493,55 @@ class Model:
                 audio = self.decode_output(out)
         return GenerationResult(audio=audio, sample_rate=self.sample_rate(), codes=out.codes, effective_lengths=out.effective_lengths)
 
+    # ---- string front ends (model/mod.rs:341-365, model/generate.rs:680-794): tokenise, then the *_full methods
+    def tokenize_text(self, text: str):
+        if self.text_processor is None:
+            raise QttsError(-5, "No text processor loaded. Load a tokenizer.json file first.")
+        return self.text_processor.tokenize_for_tts(text)
+
+    def tokenize_texts(self, texts, padding_side: str = "left"):
+        if self.text_processor is None:
+            raise QttsError(-5, "No text processor loaded. Load a tokenizer.json file first.")
+        return self.text_processor.batch_tokenize_for_tts(texts, padding_side)
+
+    def generate_custom_voice_from_text(self, text: str, speaker: str, language: str, instruct: Optional[str] = None,
+                                        options: dict = None, decode: bool = True) -> GenerationResult:
+        ins = self.text_processor.tokenize_instruct(instruct) if instruct and self.text_processor else None
+        return self.generate_custom_voice_full(self.tokenize_text(text), speaker, language, ins, options, decode)
+
+    def generate_voice_design_from_text(self, text: str, voice_description: str, language: str, options: dict = None,
+                                        decode: bool = True) -> GenerationResult:
+        ids = self.tokenize_text(text)
+        return self.generate_voice_design_full(ids, self.text_processor.tokenize_instruct(voice_description), language, options, decode)
+
+    def generate_voice_clone_from_text(self, text: str, prompt, language: str, options: dict = None, decode: bool = True) -> GenerationResult:
+        return self.generate_voice_clone_full(self.tokenize_text(text), language, prompt, options, decode)
+
+    def encode_speaker_from_mel(self, mels: Sequence[np.ndarray]) -> np.ndarray:
+        """ConditionalGeneration::encode_speaker (nn/generation.rs:140) on (frames, 128) log-mels: (batch, enc_dim)."""
+        s = self.config.get("speaker_encoder_config")
+        if not s:
+            raise QttsError(-5, "Speaker encoder not available - this model doesn't support voice cloning. "
+                                "Use a Base model for voice cloning.")
+        B = len(mels)
+        nf = np.array([len(x) for x in mels], np.int32)
+        stride = int(nf.max())
+        buf = np.zeros((B, stride, 128), np.float32)
+        for b, x in enumerate(mels):
+            buf[b, :len(x)] = x
+        emb = np.zeros((B, s["enc_dim"]), np.float32)
+        check(self.lib.qtts_speaker_embed_mel(self._m, buf.ctypes.data_as(C.c_void_p), nf.ctypes.data_as(C.c_void_p), B, stride,
+                                              emb.ctypes.data_as(C.c_void_p)))
+        return emb
+
+    def create_voice_clone_prompt_from_mel(self, mel: np.ndarray, ref_text_ids=None, x_vector_only: bool = True):
+        """Model::create_voice_clone_prompt_from_mel (model/mod.rs:579-612): speaker embedding from a (frames, 128) mel.  Like
+        the reference, the ICL variant built from a mel alone carries no reference codes."""
+        emb = self.encode_speaker_from_mel([np.asarray(mel, np.float32).reshape(-1, 128)])[0]
+        if x_vector_only:
+            return VoiceClonePromptItem.x_vector_only(emb)
+        return VoiceClonePromptItem(ref_code=None, ref_spk_embedding=emb, x_vector_only_mode=False, ref_text_ids=ref_text_ids)
+
     def generate_custom_voice_from_texts_batch(self, text_ids_list, speaker: str, language: str, options: dict = None,
                                                decode: bool = True) -> GenerationResult:
         """model/generate.rs:809-848 loops utterance by utterance; here the rows share one batched decode."""
@@ -579,6 +630,9 @@ class ModelLoader:
     def load_tts_model(self, loader: LoaderConfig = LoaderConfig()) -> Model:
         from safetensors import safe_open
         m = Model(self.config, self.codec_config if loader.load_tokenizer else None, loader, self.generate_defaults)
+        if loader.load_text_tokenizer and os.path.exists(os.path.join(self.model_dir, "tokenizer.json")):
+            from .text import TextProcessor
+            m.text_processor = TextProcessor.from_pretrained(self.model_dir)
         for path in self._tensor_files():
             with safe_open(path, framework="np") as f:
                 for key in f.keys():

@@ -55,6 +55,18 @@ def test_speaker_embedding_matches_oracle(base_f32, bind, golden):
     assert np.abs(alone[0] - emb[1]).max() < 1e-5
 
 
+def test_speaker_embedding_from_a_mel_equals_the_audio_path(base_f32):
+    """create_voice_clone_prompt_from_mel (model/mod.rs:579-612): the caller's mel through the same encoder."""
+    m, cfg = base_f32
+    clips = [make_audio(24000, 3), make_audio(17000, 4)]
+    mels = m.compute_mel_spectrogram(clips)
+    a = m.extract_speaker_embedding(clips)
+    b = m.encode_speaker_from_mel(mels)
+    assert np.abs(a - b).max() < 1e-5
+    item = m.create_voice_clone_prompt_from_mel(mels[1])
+    assert item.x_vector_only_mode and np.abs(item.ref_spk_embedding - a[1]).max() < 1e-5
+
+
 def test_speaker_embedding_feeds_generation(base_f32, bind):
     """VoiceClone (x-vector only): embedding -> one prompt position -> tokens identical to the oracle fed the oracle's embedding."""
     from golden.make_golden import GREEDY
