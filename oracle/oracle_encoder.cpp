@@ -1,6 +1,9 @@
 // CPU oracle (test infrastructure): 12.5 Hz codec ENCODER (waveform -> codes).
 // Restates qwen_tts/src/audio/encoder/{v2,seanet,transformer,quantizer}.rs.  Activations are channels-first
-// [C][T] per utterance, as in the reference.  parity unpinned: the reference holds no numeric vectors for this path.
+// [C][T] per utterance, as in the reference.  The reference holds no numeric vectors for this path; the restatement is pinned
+// instead on codes computed by an independent implementation of the same architecture (transformers' MimiModel on the same
+// synthetic weights, tests/golden/make_mimi_golden.py), adjusted for the two places where the reference departs from Mimi:
+// the stride-2 downsample conv is zero-padded (seanet.rs:244-248; Mimi replicates) and a partial last frame is dropped.
 #include "oracle_codec.hpp"
 
 #include <algorithm>

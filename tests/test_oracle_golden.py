@@ -173,3 +173,23 @@ def test_mel_and_speaker_embedding(bind, golden):
     assert mel.shape == golden["mel_1s"].shape and np.abs(mel - golden["mel_1s"]).max() < 1e-4
     e = ob.speaker_embed(mel)
     assert np.abs(e - golden["spk_embed_1s"]).max() < 1e-4
+
+
+def test_encoder_oracle_matches_an_independent_mimi_implementation(bind):
+    """The codec-encoder restatement against codes computed by transformers' MimiModel on the same synthetic weights and
+    clips (tests/golden/make_mimi_golden.py): an implementation of the same published architecture that shares no code with
+    the oracle.  The generator follows the reference in the two places where it departs from Mimi (zero-padded downsample
+    conv, no partial last frame); with those, all 34 frames x 16 codebooks are equal."""
+    import os
+    from conftest import SEED
+    from qwen3_tts_rs_amd import synth
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mimi_encoder_golden.npz"))
+    o = bind.Oracle()
+    for k, a in synth.iter_weights(synth.encoder_keys(), SEED):
+        o.load_tensor(k, a)
+    for name in ("a", "b"):
+        clip = make_audio(int(g["clip_" + name + "_len"]), int(g["clip_" + name + "_seed"]))
+        ref = g["codes_" + name]
+        got = o.encode_audio(clip, 16)
+        assert got.shape == ref.shape and len(ref) == len(clip) // 1920
+        assert np.array_equal(got, ref), name
