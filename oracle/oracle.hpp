@@ -6,11 +6,14 @@
 // library; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it,
 // and only as the checker / the reported CPU baseline.
 //
-// PARITY STATUS: "parity unpinned" for every network output.  The reference cannot be built
-// here (Rust, Candle not vendored) and its own tests pin only a handful of micro known-answer
-// vectors (MT19937/Box-Muller seed 42, logit-processor toy vectors, rotate_half, reflect_pad,
-// Hann end points, mask / position-id vectors).  Those are reproduced in tests/ against this
-// oracle; all other values are this restatement's own.
+// PARITY STATUS.  The reference cannot be built here (Rust, Candle not vendored) and its own tests pin only a handful of micro
+// known-answer vectors (MT19937/Box-Muller seed 42, logit-processor toy vectors, rotate_half, reflect_pad, Hann end points,
+// mask / position-id vectors, text normalisation); those are reproduced in tests/ against this oracle.  For the network
+// outputs the oracle is pinned instead on independent public implementations of the same architectures, run in the build
+// container on the same synthetic weights (generators and fixtures under tests/golden/): talker forward and the code-predictor
+// loop on transformers' Qwen3Model, the codec decoder on its Qwen3-Omni Code2Wav modules, the codec encoder on its MimiModel,
+// the mel front end on torch.stft.  What stays "parity unpinned" (this restatement's own values only): prompt assembly, the
+// generate loop's EOS / suppress / min-new-token rules beyond the reference's toy vectors, and the ECAPA speaker encoder.
 #pragma once
 #include <cmath>
 #include <cstdint>

@@ -193,3 +193,55 @@ def test_encoder_oracle_matches_an_independent_mimi_implementation(bind):
         got = o.encode_audio(clip, 16)
         assert got.shape == ref.shape and len(ref) == len(clip) // 1920
         assert np.array_equal(got, ref), name
+
+
+def test_codec_decoder_oracle_matches_an_independent_code2wav_implementation(bind):
+    """The codec-decoder restatement against waveforms computed by transformers' Qwen3-Omni Code2Wav modules (transformer,
+    upsampling, vocoder) on the same synthetic weights, with the front end the two models do not share written in plain torch
+    (tests/golden/make_code2wav_golden.py).  North-star bar: waveform SNR >= 40 dB; the two agree to ~110 dB."""
+    import os
+    from conftest import snr_db
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "code2wav_golden.npz"))
+    o, cfg, ccfg, tmpl = make_oracle(bind, "T0", "f32", talker=False, codec=True)
+    for name in ("a", "b"):
+        ref = g["wav_" + name]
+        w = o.codec_decode(g["codes_" + name])
+        assert len(w) == len(ref)
+        assert snr_db(ref, w) >= 90.0 and np.abs(w - ref).max() < 1e-4, name
+
+
+def test_talker_and_code_predictor_oracle_match_an_independent_qwen3_implementation(bind):
+    """Talker forward (hidden states, logits) and the greedy code-predictor loop against transformers' Qwen3Model loaded with
+    the same synthetic weights (tests/golden/make_qwen3_golden.py).  The oracle walks the reference's interleaved multimodal
+    RoPE with equal position rows, the independent model plain RoPE: their agreement is the equivalence the GPU path relies
+    on.  The code predictor's first pass is the reference's unmasked two-token prefill."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "qwen3_golden.npz"))
+    o, cfg, ccfg, tmpl = make_oracle(bind, "T0", "f32", talker=True, codec=False)
+    hid, log = o.talker_forward(g["talker_embeds"])
+    assert np.abs(hid - g["talker_hidden"]).max() < 2e-5
+    assert np.abs(log - g["talker_logits"]).max() < 2e-5
+    codes, logits = o.code_predictor(g["talker_hidden"][-1], int(g["cp_cb0"]), GREEDY)
+    assert np.array_equal(codes, g["cp_codes"])
+    assert np.abs(logits - g["cp_logits"]).max() < 2e-5
+
+
+def test_mel_oracle_matches_torch_stft(bind):
+    """mel_spectrogram (audio/mel.rs:81-158) against the same pipeline written with torch.stft: reflect padding of 384,
+    periodic Hann window of 1024, hop 256, magnitude sqrt(re^2 + im^2 + 1e-9), mel filterbank, log(clamp(., 1e-5))."""
+    import torch
+    o = bind.Oracle()
+    audio = make_audio(30000, 9)
+    mel = o.mel(audio)
+    x = torch.nn.functional.pad(torch.from_numpy(audio)[None, None], (384, 384), mode="reflect")[0]
+    spec = torch.stft(x, 1024, hop_length=256, win_length=1024, window=torch.hann_window(1024, periodic=True), center=False,
+                      return_complex=True)[0]
+    mag = torch.sqrt(spec.real ** 2 + spec.imag ** 2 + 1e-9)
+    import ctypes as C
+    fbn = np.zeros((128, 513), np.float32)                                    # pinned against librosa in test_oracle_kats
+    bind.lib().orc_mel_filterbank(1024, 128, 24000, C.c_double(0.0), C.c_double(12000.0), fbn.ctypes.data_as(C.c_void_p))
+    fb = torch.from_numpy(fbn)
+    ref = torch.log(torch.clamp(fb @ mag, min=1e-5)).T.numpy()
+    assert mel.shape == ref.shape
+    # compared before the logarithm: near the 1e-5 floor the log turns 1e-8 of rounding into 1e-3
+    assert np.abs(np.exp(mel) - np.exp(ref)).max() < 1e-5 * np.exp(ref).max()
