@@ -526,7 +526,43 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
             e.out_f32 = s.Rf.as<float>(); e.out2 = s.A.p; e.alpha_exp = blk.u[0].a1.a.as<float>(); e.beta_den = blk.u[0].a1.den.as<float>();
             epilogue(e);
         }
-        for (int u = 0; u < 3; ++u) {
+        // Residual units.  Where the fused kernel covers the block's width, each unit is one launch that reads the activated
+        // tensor from one buffer and writes the next one to the other (a block of rows reads its neighbours' rows as halo, so
+        // the unit cannot work in place); otherwise conv1 and conv2 are two launches through Bf.
+        bool fuse = true;
+        for (int u = 0; u < 3; ++u) fuse = fuse && conv_unit_supported(dt, CPo, blk.u[u].c1.taps, blk.u[u].c1.dil);
+        if (fuse) {
+            QTTS_HIP(hipMemsetAsync(s.Bf.p, 0, (size_t)(Mout + SLACK_ROWS) * CPo * es, st));
+            DevBuf* in = &s.A;
+            DevBuf* outb = &s.Bf;
+            for (int u = 0; u < 3; ++u) {
+                const CodecState::Unit& un = blk.u[u];
+                ConvEpi e{};
+                e.M = Mout; e.N = CPo; e.r = 1; e.Cout = CPo; e.bias = un.c2.bias.as<float>();
+                e.resid_f32 = s.Rf.as<float>(); e.lens = d_len(so); e.S_in = S[(size_t)so]; e.S_out = S[(size_t)so]; e.P_out = Pn; e.ld_out = CPo;
+                const Snake& nx = u < 2 ? blk.u[u + 1].a1 : (b + 1 < nb ? s.blocks[(size_t)b + 1].s0 : s.sfinal);
+                e.alpha_exp = nx.a.as<float>(); e.beta_den = nx.den.as<float>();
+                e.out_f32 = u < 2 ? s.Rf.as<float>() : nullptr;
+                e.out2 = outb->p;
+                Prof pr{};
+                if (profiling) {
+                    pr = Prof{nullptr, nullptr, Mout, CPo, un.c1.K + un.c2.K, un.c1.taps + 1, un.c1.dil};
+                    QTTS_HIP(hipEventCreate(&pr.a));
+                    QTTS_HIP(hipEventCreate(&pr.b));
+                    QTTS_HIP(hipEventRecord(pr.a, st));
+                }
+                const bool ok = launch_conv_unit(st, dt, un.c1.w.p, un.c2.w.p, (const char*)in->p + (size_t)(Pn - 6 * un.c1.dil) * CPo * es, CPo,
+                                                 un.c1.taps, un.c1.dil, un.c1.bias.as<float>(), un.a2.a.as<float>(), un.a2.den.as<float>(), e);
+                QTTS_CHECK(ok, ERR_STATE, "codec decode: fused residual unit refused a shape it reported as supported");
+                if (profiling) {
+                    QTTS_HIP(hipEventRecord(pr.b, st));
+                    prof.push_back(pr);
+                }
+                std::swap(in, outb);
+            }
+            std::swap(s.A, s.Bf);  // three units: the block's result sits in the other buffer; A names it again
+        }
+        for (int u = 0; u < 3 && !fuse; ++u) {
             const CodecState::Unit& un = blk.u[u];
             // conv1 (k = 7, dilated): A -> snake(act2) in Bf
             gemm(un.c1, (const char*)s.A.p + (size_t)(Pn - 6 * un.c1.dil) * CPo * es, Mout, CPo);

@@ -106,6 +106,46 @@ __device__ __forceinline__ void epi_pass(const ConvEpi& e, const float* otile, c
     }
 }
 
+// The same pass in two halves for kernels that have work to put between the residual loads and their use.
+template <int U>
+struct EpiRows {
+    float rr[U][4];
+    long off[U];
+    int tp[U];
+};
+template <typename T, int RT, int GPR>
+__device__ __forceinline__ void epi_rows_prefetch(const ConvEpi& e, const EpiCols& pc, const int* row_u, const int* row_tp,
+                                                  EpiRows<(RT / (256 / GPR) >= 8 ? 8 : RT / (256 / GPR))>& R) {
+    constexpr int RPI = 256 / GPR, IT = RT / RPI, U = IT >= 8 ? 8 : IT;
+    const int r0 = threadIdx.x / GPR;
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        const int row = k * RPI + r0;
+        R.tp[k] = row_tp[row];
+        R.off[k] = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) R.rr[k][q] = 0.f;
+        if (R.tp[k] >= 0) {
+            R.off[k] = conv_epi_offset(e, pc, row_u[row], R.tp[k]);
+            conv_epi_resid<T>(e, R.off[k], R.rr[k]);
+        }
+    }
+}
+template <typename T, int RT, int GPR, int OP>
+__device__ __forceinline__ void epi_rows_finish(const ConvEpi& e, const EpiCols& pc, const float* otile, const int* row_u,
+                                                EpiRows<(RT / (256 / GPR) >= 8 ? 8 : RT / (256 / GPR))>& R) {
+    constexpr int RPI = 256 / GPR, IT = RT / RPI, U = IT >= 8 ? 8 : IT;
+    const int c4 = threadIdx.x % GPR, r0 = threadIdx.x / GPR;
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        if (R.tp[k] < 0) continue;
+        const int row = k * RPI + r0;
+        const float4 a4 = *reinterpret_cast<const float4*>(otile + row * OP + 4 * c4);
+        float v[4] = {a4.x, a4.y, a4.z, a4.w};
+        conv_epi_finish<T>(e, pc, row_u[row], R.off[k], v, R.rr[k]);
+    }
+}
+
 template <typename T, int MT, int NT>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W, const T* __restrict__ X, int K, int C, int taps, int dil,
                                                         ConvEpi e) {
@@ -341,6 +381,190 @@ bool try_tile(hipStream_t st, const T* W, const T* X, int K, int C, int taps, in
     return true;
 }
 
+// One residual unit of the vocoder in one launch (audio/decoder/residual_unit.rs:11-45): x + conv1x1(Snake(conv7(xa))), where
+// xa = Snake(x) is the activated copy the previous layer left.  The 7-tap conv runs as in conv_halo_kernel; its tail
+// (bias, SnakeBeta) goes from the accumulators straight into a second LDS tile laid out as an MFMA B operand, the 1x1 conv is a
+// second, short K walk over that tile, and only then comes the epilogue that touches memory (f32 residual in / out, activated
+// copy for the next layer).  The intermediate tensor never leaves the CU, and the HBM-bound tail of one block overlaps the
+// MFMA phases of the others.  A block owns all N = C output channels (NT = C / 64 column tiles per wave).
+template <typename T, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_unit_kernel(const T* __restrict__ W1, const T* __restrict__ W2, const T* __restrict__ X, int taps,
+                                                        int dil, const float* __restrict__ bias1, const float* __restrict__ alpha2,
+                                                        const float* __restrict__ den2, ConvEpi e) {
+    using F = CFrag<T>;
+    extern __shared__ uint4 tile[];
+    constexpr int RT = 16 * MT;
+    constexpr int C = 64 * NT;
+    constexpr int VPE = 16 / (int)sizeof(T);
+    constexpr int vpr = C / VPE;
+    constexpr int cpt = C / F::CHUNK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const long m0 = (long)blockIdx.x * RT;
+    const int rows_t = RT + (taps - 1) * dil;
+    const int K = taps * C, nC = taps * cpt;
+    const int tile_slots = (max(rows_t * vpr * 16, RT * (64 * (NT % 2 == 0 ? 2 : 1) + 4) * 4) + 1023) / 1024 * 64;
+    uint4* htile = tile + tile_slots;
+    tile_load_dma<T>(tile, X + m0 * C, C, vpr, rows_t * vpr);
+    constexpr int PT = NT % 2 == 0 ? 2 : 1;
+    constexpr int CP = 64 * PT, OP = CP + 4, GPR = CP / 4;
+    constexpr int EU = (RT / (256 / GPR) >= 8 ? 8 : RT / (256 / GPR));
+    // prefetch the first pass's residual rows where that costs no occupancy (at NT = 2 it would take the third block off a CU)
+    constexpr bool ONE_ROUND = RT / (256 / GPR) == EU && sizeof(T) == 2 && NT >= 3;
+    __shared__ int row_u[RT], row_tp[RT];
+    if ((int)threadIdx.x < RT) {
+        const long m = m0 + threadIdx.x;
+        int uu = 0, tt = -1;
+        if (m < e.M) {
+            const long u = m / e.S_in;
+            const int tp = (int)(m - u * e.S_in);
+            uu = (int)u;
+            tt = tp < e.lens[u] ? tp : -1;
+        }
+        row_u[threadIdx.x] = uu;
+        row_tp[threadIdx.x] = tt;
+    }
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    constexpr int PF = MT * NT >= 12 ? 2 : 4;
+    F a[PF][NT];
+    const T* wrow[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wrow[j] = W1 + (size_t)((4 * j + wave) * 16 + r) * K + g * F::EPL;
+#pragma unroll
+    for (int s = 0; s < PF - 1; ++s)
+        if (s < nC) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) a[s][j].load(wrow[j] + (size_t)s * F::CHUNK);
+        }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    __syncthreads();
+    for (int q0 = 0; q0 < nC; q0 += PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            const int q = q0 + s;
+            if (q + PF - 1 < nC) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) a[(s + PF - 1) % PF][j].load(wrow[j] + (size_t)(q + PF - 1) * F::CHUNK);
+            }
+            if (q < nC) {
+                const int tap = q / cpt, c = q - tap * cpt;
+                const int vb = (c * F::CHUNK + g * F::EPL) / VPE;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int row = 16 * i + r + tap * dil;
+                    const uint4 h0 = tile[row * vpr + (vb ^ (row & 7))];
+                    const uint4 h1 = tile[row * vpr + ((vb + 1) ^ (row & 7))];
+                    F b;
+                    __builtin_memcpy(&b, &h0, 16);
+                    __builtin_memcpy((char*)&b + 16, &h1, 16);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[s][j], b, acc[i][j]);
+                }
+            }
+        }
+    }
+    // residual rows of the first epilogue pass and the weights of the 1x1 conv: in flight while the tail of the 7-tap conv is computed
+    EpiCols pc0;
+    EpiRows<EU> R0;
+    if constexpr (ONE_ROUND) {
+        conv_epi_cols<T>(e, 4 * ((int)threadIdx.x % GPR), pc0);
+        epi_rows_prefetch<T, RT, GPR>(e, pc0, row_u, row_tp, R0);
+    }
+    F a2[cpt][NT];
+#pragma unroll
+    for (int c = 0; c < cpt; ++c)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) a2[c][j].load(W2 + (size_t)((4 * j + wave) * 16 + r) * C + g * F::EPL + c * F::CHUNK);
+    // tail of the 7-tap conv: bias, SnakeBeta of the value the unfused layer would have stored, into the second tile.  A lane
+    // holds four consecutive channels of one row: one 8- or 16-byte store into the swizzled row-major layout.
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = (4 * j + wave) * 16 + 4 * g;
+        float bs[4], al[4], dn[4];
+        ld4(bias1 + n, bs);
+        ld4(alpha2 + n, al);
+        ld4(den2 + n, dn);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = 16 * i + r;
+            T y[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float x = to_f32<T>(from_f32<T>(acc[i][j][q] + bs[q]));
+                const float sn = snake_sin<T>(x * al[q]);
+                y[q] = from_f32<T>(x + snake_div<T>(sn * sn, dn[q]));
+            }
+            char* dst = reinterpret_cast<char*>(htile + row * vpr + ((n / VPE) ^ (row & 7))) + (n % VPE) * sizeof(T);
+            __builtin_memcpy(dst, y, 4 * sizeof(T));
+            acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < cpt; ++c) {
+        const int vb = (c * F::CHUNK + g * F::EPL) / VPE;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = 16 * i + r;
+            const uint4 h0 = htile[row * vpr + (vb ^ (row & 7))];
+            const uint4 h1 = htile[row * vpr + ((vb + 1) ^ (row & 7))];
+            F b;
+            __builtin_memcpy(&b, &h0, 16);
+            __builtin_memcpy((char*)&b + 16, &h1, 16);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a2[c][j], b, acc[i][j]);
+        }
+    }
+    // epilogue of the 1x1 conv through LDS (the input tile is dead: every wave passed the barrier above after its last read)
+    float* otile = reinterpret_cast<float*>(tile);
+#pragma unroll
+    for (int p = 0; p < NT / PT; ++p) {
+        if (p > 0) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int jj = 0; jj < PT; ++jj)
+                *reinterpret_cast<f32x4_t*>(otile + (16 * i + r) * OP + (4 * jj + wave) * 16 + 4 * g) = acc[i][p * PT + jj];
+        __syncthreads();
+        if (ONE_ROUND && p == 0) epi_rows_finish<T, RT, GPR, OP>(e, pc0, otile, row_u, R0);
+        else epi_pass<T, RT, GPR, OP>(e, otile, row_u, row_tp, p * CP);
+    }
+}
+
+bool conv_unit_supported_fwd(int dtype, int C, int taps, int dil);
+
+template <typename T, int NT>
+bool launch_unit(hipStream_t st, const T* W1, const T* W2, const T* X, int taps, int dil, const float* bias1, const float* alpha2,
+                 const float* den2, const ConvEpi& e) {
+    constexpr int MT = 4, RT = 64, C = 64 * NT, PT = NT % 2 == 0 ? 2 : 1;
+    const size_t tile_b = (std::max((size_t)(RT + (taps - 1) * dil) * C * sizeof(T), (size_t)RT * (64 * PT + 4) * 4) + 1023) / 1024 * 1024;
+    const size_t lds = tile_b + (size_t)RT * C * sizeof(T);
+    if (lds > (size_t)76 * 1024) return false;  // at least two blocks per CU
+    const long gx = (e.M + RT - 1) / RT;
+    if (gx > 0x7fffffffL) return false;
+    auto* fn = conv_unit_kernel<T, MT, NT>;
+    QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fn, dim3((unsigned)gx), dim3(256), lds, st, W1, W2, X, taps, dil, bias1, alpha2, den2, e);
+    return true;
+}
+
+template <typename T>
+bool try_unit(hipStream_t st, const T* W1, const T* W2, const T* X, int C, int taps, int dil, const float* bias1, const float* alpha2,
+              const float* den2, const ConvEpi& e) {
+    if (e.N != C || e.r != 1 || !conv_unit_supported_fwd(sizeof(T) == 2 ? BF16 : F32, C, taps, dil)) return false;
+    if (C == 64) return launch_unit<T, 1>(st, W1, W2, X, taps, dil, bias1, alpha2, den2, e);
+    if (C == 128) return launch_unit<T, 2>(st, W1, W2, X, taps, dil, bias1, alpha2, den2, e);
+    if (C == 192) return launch_unit<T, 3>(st, W1, W2, X, taps, dil, bias1, alpha2, den2, e);
+    if constexpr (sizeof(T) == 2) {
+        if (C == 256) return launch_unit<T, 4>(st, W1, W2, X, taps, dil, bias1, alpha2, den2, e);
+    }
+    return false;
+}
+
 template <typename T, int MT, int NT>
 void launch_halo(hipStream_t st, const T* W, const T* X, int K, int C, int taps, int dil, const ConvEpi& e, size_t lds) {
     const long RT = 16 * MT;
@@ -396,6 +620,31 @@ bool launch_conv_halo(hipStream_t st, int dtype, const void* W, const void* X, i
     }
     if (try_tile<float>(st, (const float*)W, (const float*)X, K, C, taps, (int)dil, e)) return true;
     return try_halo<float>(st, (const float*)W, (const float*)X, K, C, taps, (int)dil, e);
+}
+
+// Shapes the fused residual unit covers: 64 / 128 / 192 (bf16: / 256) channels with a tile that leaves two blocks per CU.
+bool conv_unit_supported(int dtype, int C, int taps, int dil) {
+    static const bool off = getenv("QTTS_CONV_UNIT") && atoi(getenv("QTTS_CONV_UNIT")) == 0;
+    if (off || taps < 1 || dil < 1 || dil > 64) return false;
+    if (!(C == 64 || C == 128 || C == 192 || (C == 256 && dtype == BF16))) return false;
+    const size_t es = dtype == BF16 ? 2 : 4;
+    const int PT = (C / 64) % 2 == 0 ? 2 : 1;
+    const size_t tile_b = (std::max((size_t)(64 + (taps - 1) * dil) * C * es, (size_t)64 * (64 * PT + 4) * 4) + 1023) / 1024 * 1024;
+    return tile_b + (size_t)64 * C * es <= (size_t)76 * 1024;
+}
+
+namespace {
+bool conv_unit_supported_fwd(int dtype, int C, int taps, int dil) { return conv_unit_supported(dtype, C, taps, dil); }
+}  // namespace
+
+// Fused residual unit: conv (taps, dilation; W1 [C][taps * C]) + bias1 + SnakeBeta(alpha2, den2), then the 1x1 conv W2 [C][C] with the
+// epilogue e (bias, f32 residual, outputs).  X as for launch_conv_halo.  False = shape not covered (the caller launches the two
+// convs one after the other).
+bool launch_conv_unit(hipStream_t st, int dtype, const void* W1, const void* W2, const void* X, int C, int taps, int dil, const float* bias1,
+                      const float* alpha2, const float* den2, const ConvEpi& e) {
+    QTTS_CHECK(W1 && W2 && X && bias1 && alpha2 && den2 && e.lens && e.M >= 1 && e.S_in >= 1, ERR_BAD_ARG, "conv_unit: null argument");
+    if (dtype == BF16) return try_unit<bf16_t>(st, (const bf16_t*)W1, (const bf16_t*)W2, (const bf16_t*)X, C, taps, dil, bias1, alpha2, den2, e);
+    return try_unit<float>(st, (const float*)W1, (const float*)W2, (const float*)X, C, taps, dil, bias1, alpha2, den2, e);
 }
 
 }  // namespace qtts
