@@ -50,7 +50,7 @@ struct Frag<float> {
     }
 };
 
-template <typename T, int MT, int NT, bool FAKEX = false>
+template <typename T, int MT, int NT>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ W, const T* __restrict__ X,
                                                           float* __restrict__ out, int N, int K, int KS, int ldx,
                                                           long out_ks_stride) {
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ 
 #pragma unroll
         for (int j = 0; j < NT; ++j) a[j].load(wp[j] + off);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) b[i].load(xp[i] + (FAKEX ? 0 : off));
+        for (int i = 0; i < MT; ++i) b[i].load(xp[i] + off);
     };
     auto mma_stage = [&](const F(&a)[NT], const F(&b)[MT]) {
 #pragma unroll
@@ -206,14 +206,9 @@ static void launch_mt(hipStream_t st, const T* W, const T* X, float* out, int Mp
     const int Z = Mpad / (16 * MT);
     const long kstride = (long)Mpad * N;
     static const int dbg_nt = getenv("QTTS_GEMM_NT") ? atoi(getenv("QTTS_GEMM_NT")) : 0;
-    static const int dbg_fx = getenv("QTTS_GEMM_FAKEX") ? atoi(getenv("QTTS_GEMM_FAKEX")) : 0;
     if (dbg_nt == 4 && N % 64 == 0) {
         dim3 grid(N / 64, KS, Z);
-        if (dbg_fx) hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 4, true>), grid, dim3(256), 0, st, W, X, out, N, K, KS, ldx, kstride);
-        else hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 4>), grid, dim3(256), 0, st, W, X, out, N, K, KS, ldx, kstride);
-    } else if (dbg_fx && N % 32 == 0) {
-        dim3 grid(N / 32, KS, Z);
-        hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 2, true>), grid, dim3(256), 0, st, W, X, out, N, K, KS, ldx, kstride);
+        hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 4>), grid, dim3(256), 0, st, W, X, out, N, K, KS, ldx, kstride);
     } else if (N % 32 == 0 && (long)(N / 32) * KS * Z >= 256) {
         dim3 grid(N / 32, KS, Z);
         hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 2>), grid, dim3(256), 0, st, W, X, out, N, K, KS, ldx, kstride);
