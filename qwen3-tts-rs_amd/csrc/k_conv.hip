@@ -16,6 +16,8 @@ namespace qtts {
 
 namespace {
 
+constexpr int LDS_CEILING = 152 * 1024;  // dynamic LDS any kernel here may ask for (160 KB per CU on gfx950, minus the static arrays)
+
 template <typename T>
 struct CFrag;
 template <>
@@ -350,7 +352,8 @@ void launch_tile(hipStream_t st, const T* W, const T* X, int K, int C, int taps,
     const size_t lds = (std::max((size_t)(RT + (taps - 1) * dil) * cph * sizeof(T), (size_t)RT * (16 * WN * PT + 4) * 4) + 1023) / 1024 * 1024;
     const long gy = (e.M + RT - 1) / RT;
     auto* fn = conv_tile_kernel<T, MT, NT, WN>;
-    QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // the same ceiling from every caller: streams of several host threads launch this kernel with different tile sizes
+    QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_CEILING));
     hipLaunchKernelGGL(fn, dim3(e.N / (16 * NT * WN), (unsigned)gy), dim3(256), lds, st, W, X, K, C, taps, dil, cph, e);
 }
 
@@ -547,7 +550,7 @@ bool launch_unit(hipStream_t st, const T* W1, const T* W2, const T* X, int taps,
     const long gx = (e.M + RT - 1) / RT;
     if (gx > 0x7fffffffL) return false;
     auto* fn = conv_unit_kernel<T, MT, NT>;
-    QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_CEILING));
     hipLaunchKernelGGL(fn, dim3((unsigned)gx), dim3(256), lds, st, W1, W2, X, taps, dil, bias1, alpha2, den2, e);
     return true;
 }
