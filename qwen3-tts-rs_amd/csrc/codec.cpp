@@ -347,6 +347,12 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
     auto d_len = [&](int i) { return d_meta + o_len[(size_t)i]; };
     auto d_lenm1 = [&](int i) { return d_meta + o_lenm1[(size_t)i]; };
 
+    // Only the leading rows of every strip (the causal padding the next conv reads) must be zero: rows past a strip's valid
+    // length are never read by a valid row, and whatever a tile computes from them is masked in the epilogue.
+    auto zero_pad_rows = [&](void* buf, long S_rows, int P_rows, int C) {
+        if (P_rows > 0)
+            QTTS_HIP(hipMemset2DAsync(buf, (size_t)S_rows * C * es, 0, (size_t)P_rows * C * es, (size_t)U, st));
+    };
     s.A.ensure(g.act_elems * es);
     s.Bf.ensure(g.act_elems * es);
     s.R.ensure(g.act_elems * es);
@@ -465,7 +471,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         const int Pn = P[(size_t)i + 1];
         // transposed conv (kernel == stride): A -> R (strips with six leading zero rows for the depthwise conv)
         gemm(up.ct, (const char*)s.A.p + (size_t)Pcur * s.latP * es, Min, s.latP);
-        QTTS_HIP(hipMemsetAsync(s.R.p, 0, (size_t)(Mout + SLACK_ROWS) * s.latP * es, st));
+        zero_pad_rows(s.R.p, S[(size_t)i + 1], Pn, s.latP);
         {
             ConvEpi e{};
             e.M = Min; e.N = up.ct.N; e.r = up.ct.r; e.Cout = up.ct.CoutP; e.bias = up.ct.bias.as<float>();
@@ -518,7 +524,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         const int Pn = P[(size_t)so];
         const int CPo = blk.ct.CoutP;
         gemm(blk.ct, xin, Min, CP);
-        QTTS_HIP(hipMemsetAsync(s.A.p, 0, (size_t)(Mout + SLACK_ROWS) * CPo * es, st));
+        zero_pad_rows(s.A.p, S[(size_t)so], Pn, CPo);
         {
             ConvEpi e{};
             e.M = Min; e.N = blk.ct.N; e.r = blk.ct.r; e.Cout = CPo; e.bias = blk.ct.bias.as<float>();
@@ -532,7 +538,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         bool fuse = true;
         for (int u = 0; u < 3; ++u) fuse = fuse && conv_unit_supported(dt, CPo, blk.u[u].c1.taps, blk.u[u].c1.dil);
         if (fuse) {
-            QTTS_HIP(hipMemsetAsync(s.Bf.p, 0, (size_t)(Mout + SLACK_ROWS) * CPo * es, st));
+            zero_pad_rows(s.Bf.p, S[(size_t)so], Pn, CPo);
             DevBuf* in = &s.A;
             DevBuf* outb = &s.Bf;
             for (int u = 0; u < 3; ++u) {

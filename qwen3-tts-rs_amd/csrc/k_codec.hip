@@ -105,76 +105,85 @@ void launch_dwconv_ln(hipStream_t st, int dtype, const void* x, const float* w, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Final conv (C -> 1, k = 7, causal) + clamp[-1, 1] (decoder/v2.rs:238-246).  A block produces 64 consecutive samples:
-// their 70 input rows are staged in LDS with 16-byte loads (each row is shared by up to 7 samples), four lanes share a
-// sample (a quarter of the channels each).
+// Final conv (C -> 1, k = 7, causal) + clamp[-1, 1] (decoder/v2.rs:238-246).  A block produces 128 consecutive samples: their
+// 134 input rows are staged in LDS with 16-byte loads.  A thread computes FOUR consecutive samples over an eighth of the
+// channels, so a weight read from LDS feeds four samples and an input row up to four taps; eight lanes share a sample group.
+// (64 samples per block in f32 runs, whose rows are twice as wide)
 template <typename T>
 __global__ __launch_bounds__(256) void final_conv_kernel(const T* __restrict__ x, const float* __restrict__ w /*[7][C]*/, float bias,
                                                          const int* __restrict__ nvalid, long S, int P, int C, float* wav,
                                                          long wav_stride) {
+    constexpr int FC_SAMPLES = sizeof(T) == 2 ? 128 : 64, FC_ROWS = FC_SAMPLES + 6;
     extern __shared__ __align__(16) unsigned char smem[];
     const int u = blockIdx.y;
-    const long t0 = (long)blockIdx.x * 64;
+    const long t0 = (long)blockIdx.x * FC_SAMPLES;
     const int n = nvalid[u];
     if (t0 >= n) return;
     const int row_bytes = C * (int)sizeof(T), pitch = row_bytes + 16;  // +16: consecutive rows start 4 banks apart
     const int vpr = row_bytes / 16;
-    float* wl = reinterpret_cast<float*>(smem + 70 * pitch);
+    float* wl = reinterpret_cast<float*>(smem + FC_ROWS * pitch);
     const unsigned char* src = reinterpret_cast<const unsigned char*>(x + ((long)u * S + P + t0 - 6) * C);
     // four loads in flight per thread before the first LDS store (a load-store-load chain would pay the memory latency per vector)
-    for (int base = 0; base < 70 * vpr; base += 1024) {
+    for (int base = 0; base < FC_ROWS * vpr; base += 1024) {
         uint4 buf[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int v = base + k * 256 + (int)threadIdx.x;
-            if (v < 70 * vpr) buf[k] = *reinterpret_cast<const uint4*>(src + (long)(v / vpr) * row_bytes + (v % vpr) * 16);
+            if (v < FC_ROWS * vpr) buf[k] = *reinterpret_cast<const uint4*>(src + (long)(v / vpr) * row_bytes + (v % vpr) * 16);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int v = base + k * 256 + (int)threadIdx.x;
-            if (v < 70 * vpr) *reinterpret_cast<uint4*>(smem + (v / vpr) * pitch + (v % vpr) * 16) = buf[k];
+            if (v < FC_ROWS * vpr) *reinterpret_cast<uint4*>(smem + (v / vpr) * pitch + (v % vpr) * 16) = buf[k];
         }
     }
-    for (int base = 0; base < 7 * C; base += 1024) {
-        float wb[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = base + k * 256 + (int)threadIdx.x;
-            if (i < 7 * C) wb[k] = w[i];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = base + k * 256 + (int)threadIdx.x;
-            if (i < 7 * C) wl[i] = wb[k];
-        }
-    }
+    for (int i = threadIdx.x; i < 7 * C; i += 256) wl[i] = w[i];
     __syncthreads();
-    const int sidx = threadIdx.x >> 2, part = threadIdx.x & 3;
-    const int cq = C / 4, c0 = part * cq;
-    float acc = 0.f;
-    for (int k = 0; k < 7; ++k) {
-        const T* row = reinterpret_cast<const T*>(smem + (sidx + k) * pitch) + c0;
-        const float* wk = wl + k * C + c0;
-        for (int c = 0; c < cq; c += 8) {
-            float xv[8];
-            load8(row + c, xv);
+    const int sg = threadIdx.x >> 3, slice = threadIdx.x & 7;
+    if (4 * sg >= FC_SAMPLES) return;
+    const int cs = C / 8, c0 = slice * cs;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < cs; c += 8) {
+        float wk[7][8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc += xv[q] * wk[c + q];
+        for (int k = 0; k < 7; ++k) load8(wl + k * C + c0 + c, wk[k]);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            float xv[8];
+            load8(reinterpret_cast<const T*>(smem + (4 * sg + r) * pitch) + c0 + c, xv);
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int k = r - sidx;  // sample 4 sg + sidx reads rows 4 sg + sidx .. + 6
+                if (k >= 0 && k <= 6) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[sidx] += xv[q] * wk[k][q];
+                }
+            }
         }
     }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    const long t = t0 + sidx;
-    if (t < n && part == 0) wav[(long)u * wav_stride + t] = fminf(1.0f, fmaxf(-1.0f, acc + bias));
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) {
+        acc[sidx] += __shfl_xor(acc[sidx], 1, 64);
+        acc[sidx] += __shfl_xor(acc[sidx], 2, 64);
+        acc[sidx] += __shfl_xor(acc[sidx], 4, 64);
+    }
+    if (slice == 0) {
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const long t = t0 + 4 * sg + sidx;
+            if (t < n) wav[(long)u * wav_stride + t] = fminf(1.0f, fmaxf(-1.0f, acc[sidx] + bias));
+        }
+    }
 }
 
 void launch_final_conv(hipStream_t st, int dtype, const void* x, const float* w, float bias, const int* nvalid, int U, long Tmax, long S,
                        int P, int C, float* wav, long wav_stride) {
-    QTTS_CHECK(P >= 6 && C % 32 == 0 && U >= 1 && Tmax >= 1, ERR_SHAPE, "final_conv: needs six padding rows and a channel count that is a multiple of 32");
+    QTTS_CHECK(P >= 6 && C % 64 == 0 && U >= 1 && Tmax >= 1, ERR_SHAPE, "final_conv: needs six padding rows and a channel count that is a multiple of 64");
     const size_t es = dtype == BF16 ? 2 : 4;
-    const size_t lds = 70 * ((size_t)C * es + 16) + (size_t)7 * C * 4;
+    const int per_block = dtype == BF16 ? 128 : 64;
+    const size_t lds = (size_t)(per_block + 6) * ((size_t)C * es + 16) + (size_t)7 * C * 4;
     QTTS_CHECK(lds <= 64 * 1024, ERR_SHAPE, "final_conv: too many channels for the LDS staging buffer");
-    dim3 grid((unsigned)((Tmax + 63) / 64), U);
+    dim3 grid((unsigned)((Tmax + per_block - 1) / per_block), U);
     if (dtype == BF16) hipLaunchKernelGGL(final_conv_kernel<bf16_t>, grid, dim3(256), lds, st, (const bf16_t*)x, w, bias, nvalid, S, P, C, wav, wav_stride);
     else hipLaunchKernelGGL(final_conv_kernel<float>, grid, dim3(256), lds, st, (const float*)x, w, bias, nvalid, S, P, C, wav, wav_stride);
 }
