@@ -50,7 +50,7 @@ def test_long_prompt_spans_several_prefill_chunks(bind):
     from qwen3_tts_rs_amd import synth
     m, o, cfg, tmpl = _pair(bind)
     try:
-        texts = [synth.synthetic_text_ids(tmpl, n, i) for i, n in enumerate([1300, 40, 700])]   # 2000+ prompt positions in one batch
+        texts = [synth.synthetic_text_ids(tmpl, n, i) for i, n in enumerate([3700, 40, 700])]   # 4400+ prompt positions in one batch: more than one prefill pass of 4096
         _check(bind, m, o, cfg, texts, BASE, 6)
     finally:
         m.close()
