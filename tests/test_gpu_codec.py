@@ -113,3 +113,16 @@ def test_full_size_codec_properties(dtype, causal_db):
         assert snr_db(m.decode_codes(codes[:1, :100])[0], ch[:100 * up - 555]) > causal_db
     finally:
         m.close()
+
+
+def test_decode_matches_the_independent_code2wav_golden(codec_f32):
+    """The GPU decoder against waveforms from transformers' Code2Wav modules on the same weights (tests/golden/
+    make_code2wav_golden.py) - the same fixture that pins the CPU oracle, with no oracle in between."""
+    import os
+    m, ccfg = codec_f32
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "code2wav_golden.npz"))
+    for name in ("a", "b"):
+        w = m.decode_codes(g["codes_" + name][None])[0]
+        ref = g["wav_" + name]
+        assert len(w) == len(ref)
+        assert snr_db(ref, w) >= 80.0 and np.abs(w - ref).max() < 1e-4, name

@@ -47,6 +47,29 @@ def test_encoder_codes_match_oracle_f32(enc_oracle):
         m.close()
 
 
+def test_encoder_codes_match_the_independent_mimi_golden():
+    """The GPU encoder against codes from transformers' MimiModel on the same weights (tests/golden/make_mimi_golden.py),
+    with no oracle in between; frames are compared up to and including their first difference (near-ties)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mimi_encoder_golden.npz"))
+    m, cfg, ccfg, tmpl = _model("f32")
+    try:
+        total = same = 0
+        for name in ("a", "b"):
+            clip = make_audio(int(g["clip_" + name + "_len"]), int(g["clip_" + name + "_seed"]))
+            ref = g["codes_" + name]
+            got = m.encode_audio([clip], 16)[0]
+            assert got.shape == ref.shape
+            for t in range(len(ref)):
+                diff = np.nonzero(ref[t] != got[t])[0]
+                n = 16 if len(diff) == 0 else diff[0] + 1
+                total += n
+                same += n if len(diff) == 0 else n - 1
+        assert same / total > 0.99, (same, total)
+    finally:
+        m.close()
+
+
 def test_encoder_rejects_short_clips_and_missing_weights():
     from qwen3_tts_rs_amd import QttsError, synthetic_model
     m, cfg, ccfg, tmpl = _model("f32")
