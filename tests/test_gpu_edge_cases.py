@@ -136,3 +136,28 @@ def test_mid_size_codec_f32(bind):
             assert len(ref) == len(wavs[b]) and snr_db(ref, wavs[b]) >= 40.0
     finally:
         m.close()
+
+
+def test_string_front_ends_tokenise_then_generate(bind, tmp_path):
+    """generate_*_from_text (model/generate.rs:680-794): text -> chat template -> ids -> the *_full path.  The tokenizer is a
+    toy byte-level BPE written in the tokenizer.json format (its ids stay inside T0's small text vocabulary)."""
+    from test_text_front_end import _toy_tokenizer
+    from qwen3_tts_rs_amd import QttsError
+    from qwen3_tts_rs_amd.text import TextProcessor
+    m, o, cfg, tmpl = _pair(bind)
+    try:
+        with pytest.raises(QttsError, match="No text processor loaded"):
+            m.generate_custom_voice_from_text("hello world", "speaker1", "english")
+        _toy_tokenizer(str(tmp_path / "tokenizer.json"))
+        m.text_processor = TextProcessor.from_pretrained(str(tmp_path))
+        opts = dict(max_new_tokens=6, do_sample=False, subtalker_do_sample=False, temperature=1.0)
+        ids = m.tokenize_text("hello world speak slowly")
+        assert max(ids) < cfg["talker_config"]["text_vocab_size"] and len(ids) > 8
+        a = m.generate_custom_voice_from_text("hello world speak slowly", "speaker1", "english", options=opts, decode=False)
+        b = m.generate_custom_voice_full(ids, "speaker1", "english", options=opts, decode=False)
+        assert np.array_equal(a.codes, b.codes) and a.codes.shape[1] >= 1
+        r = o.generate(np.asarray(ids, np.uint32), bind.resolve_codec_prefill(cfg, "english", "speaker1"), BASE, 6,
+                       speaker_token=bind.resolve_speaker_token(cfg, "speaker1"))
+        assert np.array_equal(r["codes"], a.codes[0][:r["num_steps"]])
+    finally:
+        m.close()
