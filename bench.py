@@ -129,10 +129,17 @@ def main():
     import torch.distributed as dist
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    # QTTS_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks then share devices)
+    backend = os.environ.get("QTTS_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import threading
     from qwen3_tts_rs_amd import SamplingConfig, synth
@@ -207,7 +214,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    elapsed_max, audio_total = reduce_job(elapsed, stats["audio_s"], dist if world > 1 else None, f"cuda:{local}")
+    elapsed_max, audio_total = reduce_job(elapsed, stats["audio_s"], dist if world > 1 else None, f"cuda:{local}" if backend == "nccl" else "cpu")
 
     result = None
     if rank == 0:
