@@ -1,10 +1,11 @@
 """Developer scratch: turn the files a profiling run left under gpurun_out/ into the committed summaries under profiles/."""
-import csv, json, re, shutil
+import csv, json, re, shutil, sys
+LABEL = sys.argv[1] if len(sys.argv) > 1 else "final"   # heading and file prefix of the summaries, e.g. "r01"
 rows = list(csv.DictReader(open('gpurun_out/p_bench_kernel_stats.csv')))
 frames = 720.0
 with open('profiles/r01_final_bench_kernel_stats_summary.txt', 'w') as f:
     p = lambda *a: print(*a, file=f)
-    p("# Round 1 (final) - rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 3 --warmup 3 --frames 120 --no-cpu-baseline`")
+    p(f"# {LABEL} - rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 3 --warmup 3 --frames 120 --no-cpu-baseline`")
     p("# (S17 shape set, bf16, batch 64 per step, 3 batches in flight on 3 streams, one MI355X; same shape as the default run, fewer frames).")
     p("# Per-frame columns divide by the 720 decode frames of the 6 steps (the isolated codec decode of the roofline leg adds a little).")
     p("# Batch-1 and codec-only tables: r01_batch1_S06_kernel_stats_summary.txt, r01_codec_conv_profile.txt.")
@@ -17,7 +18,7 @@ with open('profiles/r01_final_bench_kernel_stats_summary.txt', 'w') as f:
 shutil.copy('gpurun_out/p_bench_kernel_stats.csv', 'profiles/r01_final_bench_kernel_stats.csv')
 shutil.copy('gpurun_out/p_codec_kernel_stats.csv', 'profiles/r01_codec_kernel_stats.csv')
 with open('profiles/r01_codec_conv_profile.txt', 'w') as f:
-    f.write("# Round 1 (final) - codec decoder, 64 utterances x 375 frames, bf16, default codec shape: HIP-event time of every conv launch\n"
+    f.write(f"# {LABEL} - codec decoder, 64 utterances x 375 frames, bf16, default codec shape: HIP-event time of every conv launch\n"
             "# (QTTS_CODEC_PROFILE=1 python3 tools/dev/dev_codec_prof.py; two groups of utterances per decode; the second repetition is shown).\n"
             "# taps = 8 rows are fused residual units (7-tap conv + SnakeBeta + 1x1 conv + residual, one launch); 'in+out' = (input + output channels) x rows x 2 B / time.\n"
             "# History of the same decode: 868 ms (first version) -> 468 (cheaper epilogue math) -> 361 (DMA tile load, batched epilogue loads) -> 335 (fused units) -> 327.\n")
