@@ -161,12 +161,17 @@ def main():
     out_last = [None]
     lock = threading.Lock()
 
+    csize = ccfg["decoder_config"]["codebook_size"]
+
     def step(mod, record):
         t_s = time.perf_counter()
         first_ms = []
 
         def on_first(codes):
             # streaming decode session: the samples this push returns (1920 n - 555) are exactly those of the whole decode
+            # a row that already produced EOS (a cb0 outside the codebook) has no audio from that frame on: feed silence codes
+            done = np.maximum.accumulate(codes[:, :, 0] >= csize, axis=1)
+            codes = np.where(done[:, :, None], 0, codes).astype(np.uint32)
             with mod.open_codec_stream(codes.shape[0], codes.shape[1]) as cs:
                 cs.push(codes)
             first_ms.append((time.perf_counter() - t_s) * 1e3)
