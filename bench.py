@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
     ap.add_argument("--frames", type=int, default=375, help="frames generated per utterance (30 s of audio)")
     ap.add_argument("--greedy", action="store_true", help="CLI --greedy semantics instead of seeded sampling")
+    ap.add_argument("--natural-eos", action="store_true",
+                    help="let rows end where the model says EOS (the reference's rule); the default keeps EOS suppressed for --frames "
+                         "frames so that every row of every run produces the same fixed length")
     ap.add_argument("--no-codec", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the decode frame kernel by kernel (counter collection cannot follow hipGraphs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -178,7 +181,7 @@ def main():
 
         stream_first = not args.no_codec and 2 < args.first_frames < args.frames
         out = mod.generate(reqs, sampling, args.frames, use_graph=not args.no_graph, first_frames=args.first_frames if stream_first else 0,
-                           on_first_chunk=on_first if stream_first else None)
+                           on_first_chunk=on_first if stream_first else None, min_new_tokens=0 if args.natural_eos else args.frames)
         wavs = [] if args.no_codec else mod.decode_output(out)
         if record:
             with lock:
@@ -275,9 +278,11 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.shape} CustomVoice-shaped random-init model, batch {args.batch} synthetic texts per GPU, "
-                                   f"{args.frames} frames each ({'greedy' if args.greedy else 'seeded sampling'}), codec decode "
+                                   f"{args.frames} frames each ({'greedy' if args.greedy else 'seeded sampling'}, "
+                                   f"{'EOS as sampled' if args.natural_eos else 'EOS suppressed up to that length'}), codec decode "
                                    f"{'off' if args.no_codec else 'to 24 kHz waveforms on the host'}",
-                       "batch_per_gpu": args.batch, "frames": args.frames, "parallelism": f"dp{world} (per-utterance)"},
+                       "batch_per_gpu": args.batch, "frames": args.frames, "fixed_length": not args.natural_eos,
+                       "parallelism": f"dp{world} (per-utterance)"},
             # first audio = the first `first_frames` frames through a streaming decode session (final samples), decoded and on the
             # host while generation continues; full utterance = the reference's own (non-streaming) definition
             "p50_first_audio_ms": round(float(np.median(stats["first_ms"])), 1), "first_audio_frames": args.first_frames,

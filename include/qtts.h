@@ -114,6 +114,10 @@ typedef struct {
     int first_frames;
     void (*chunk_cb)(void* user, const uint32_t* codes, int n, int frames);
     void* chunk_user;
+    /* Throughput-measurement protocol (no counterpart in the reference): EOS stays suppressed until this many frames exist,
+     * so that every row of a benchmark run produces the same fixed length.  0 = the reference's min_new_tokens = 2
+     * (nn/sampling.rs:55 via nn/generation.rs:841-842). */
+    int min_new_tokens;
 } qtts_gen_debug;
 
 /* ConditionalGeneration::generate (nn/generation.rs:815-1194) for n independent utterances decoded as

@@ -418,7 +418,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         a.suppress_lo = talker ? std::max(0, V - 1024) : 0;
         a.suppress_hi = talker ? V : 0;
         a.eos_id = talker ? c.eos : -1;
-        a.min_new_tokens = talker ? 2 : 0;  // sampling.rs:55 via generation.rs:841-842; subtalker: sampling.rs:117
+        a.min_new_tokens = talker ? (dbg && dbg->min_new_tokens > 0 ? dbg->min_new_tokens : 2) : 0;  // sampling.rs:55 via generation.rs:841-842; subtalker: sampling.rs:117
         a.step = d_step; a.uniforms = g.uniforms.as<float>(); a.codes_base = g.codes.as<unsigned>(); a.row_stride = row_stride;
         a.G = G; a.g = gcol; a.eos_step = talker ? g.eos_step.as<int>() : nullptr;
         launch_sample(st, a);

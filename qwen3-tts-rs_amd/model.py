@@ -247,10 +247,11 @@ class Model:
     # ------------------------------------------------------------------ generation
     def generate(self, requests: Sequence[GenerationRequest], sampling: SamplingConfig, max_new_tokens: int,
                  trace: bool = False, use_graph: bool = True, profile_gemm: bool = False, first_frames: int = 0,
-                 on_first_chunk=None) -> Output:
+                 on_first_chunk=None, min_new_tokens: int = 0) -> Output:
         """ConditionalGeneration::generate (nn/generation.rs:815) over a batch of independent utterances.
         on_first_chunk(codes (batch, first_frames, groups)) is called once the first `first_frames` frames of every row
-        exist, while generation continues afterwards (first-audio hook; the reference has no counterpart)."""
+        exist, while generation continues afterwards (first-audio hook; the reference has no counterpart).
+        min_new_tokens > 0 keeps EOS suppressed for that many frames (fixed-length throughput runs; 0 = the reference's 2)."""
         n = len(requests)
         G = self.num_code_groups
         V = self.config["talker_config"]["vocab_size"]
@@ -302,6 +303,7 @@ class Model:
             dbg.hidden = hidden.ctypes.data_as(C.POINTER(C.c_float))
         dbg.use_graph = int(use_graph)
         dbg.profile_gemm = int(profile_gemm)
+        dbg.min_new_tokens = int(min_new_tokens)
         cb_err = []
         if on_first_chunk is not None and first_frames > 0:
             def _cb(_user, ptr, nrows, frames):

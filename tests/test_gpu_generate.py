@@ -61,6 +61,13 @@ def test_eos_handling(golden):
         assert out.num_steps == int(golden["eos_num_steps"])
         assert out.effective_lengths == [int(golden["eos_effective_len"])]
         assert np.array_equal(out.codes[0], golden["eos_codes"])
+        # fixed-length measurement protocol: EOS stays suppressed for min_new_tokens frames, the frames before the
+        # reference's EOS step are unchanged and the run goes on to the requested length
+        k = int(golden["eos_effective_len"])
+        fixed = m.generate([_req(golden["text_ids"])], _sampling(GREEDY), 64, min_new_tokens=64)
+        assert fixed.num_steps == 64 and fixed.effective_lengths == [64]
+        assert np.array_equal(fixed.codes[0][:k], golden["eos_codes"][:k])
+        assert (fixed.codes[0][:, 0] != int(golden["eos_id"])).all()
     finally:
         m.close()
 
