@@ -12,8 +12,9 @@
 // outputs the oracle is pinned instead on independent public implementations of the same architectures, run in the build
 // container on the same synthetic weights (generators and fixtures under tests/golden/): talker forward and the code-predictor
 // loop on transformers' Qwen3Model, the codec decoder on its Qwen3-Omni Code2Wav modules, the codec encoder on its MimiModel,
-// the mel front end on torch.stft.  What stays "parity unpinned" (this restatement's own values only): prompt assembly, the
-// generate loop's EOS / suppress / min-new-token rules beyond the reference's toy vectors, and the ECAPA speaker encoder.
+// the speaker encoder on its ECAPA_TimeDelayNet (Qwen2.5-Omni), the mel front end on torch.stft.  What stays "parity unpinned"
+// (this restatement's own values only): prompt assembly and the generate loop's EOS / suppress / min-new-token rules beyond
+// the reference's toy vectors.
 #pragma once
 #include <cmath>
 #include <cstdint>

@@ -1,5 +1,6 @@
 // CPU oracle (test infrastructure): ECAPA-TDNN speaker encoder and log-mel front end.
-// Restates qwen_tts/src/nn/speaker_encoder.rs and qwen_tts/src/audio/mel.rs.
+// Restates qwen_tts/src/nn/speaker_encoder.rs and qwen_tts/src/audio/mel.rs.  Pinned on transformers' ECAPA_TimeDelayNet
+// (tests/golden/make_ecapa_golden.py, 2e-6 max-abs) and on a torch.stft pipeline (tests/test_oracle_golden.py).
 #include "oracle_codec.hpp"
 
 #include <algorithm>

@@ -67,6 +67,17 @@ def test_speaker_embedding_from_a_mel_equals_the_audio_path(base_f32):
     assert item.x_vector_only_mode and np.abs(item.ref_spk_embedding - a[1]).max() < 1e-5
 
 
+def test_speaker_embedding_matches_an_independent_ecapa_implementation(base_f32):
+    """The device encoder against transformers' ECAPA_TimeDelayNet on the same weights and mel inputs
+    (tests/golden/make_ecapa_golden.py, committed as tests/golden/ecapa_golden.npz)."""
+    import os
+    m, cfg = base_f32
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ecapa_golden.npz"))
+    e = m.encode_speaker_from_mel([g["mel_a"], g["mel_b"]])
+    for i, name in enumerate(("a", "b")):
+        assert np.abs(e[i] - g["emb_" + name]).max() < 1e-4, name
+
+
 def test_speaker_embedding_feeds_generation(base_f32, bind):
     """VoiceClone (x-vector only): embedding -> one prompt position -> tokens identical to the oracle fed the oracle's embedding."""
     from golden.make_golden import GREEDY

@@ -245,3 +245,15 @@ def test_mel_oracle_matches_torch_stft(bind):
     assert mel.shape == ref.shape
     # compared before the logarithm: near the 1e-5 floor the log turns 1e-8 of rounding into 1e-3
     assert np.abs(np.exp(mel) - np.exp(ref)).max() < 1e-5 * np.exp(ref).max()
+
+
+def test_speaker_encoder_oracle_matches_an_independent_ecapa_implementation(bind):
+    """The ECAPA-TDNN restatement (nn/speaker_encoder.rs) against embeddings computed by transformers' ECAPA_TimeDelayNet
+    (the Qwen2.5-Omni speaker encoder: same blocks, same weight keys) on the same synthetic weights and mel inputs of two
+    lengths (tests/golden/make_ecapa_golden.py).  The two agree to ~2e-6 on values of magnitude 5."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ecapa_golden.npz"))
+    ob, _, _, _ = make_oracle(bind, "T0", "f32", model_type="base", talker=True, codec=False)
+    for name in ("a", "b"):
+        e = ob.speaker_embed(g["mel_" + name])
+        assert e.shape == g["emb_" + name].shape and np.abs(e - g["emb_" + name]).max() < 2e-5, name
