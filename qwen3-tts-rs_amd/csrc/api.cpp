@@ -1,6 +1,7 @@
 // C ABI of libqtts_hip (declared in include/qtts.h).  Exceptions never cross the boundary: they are
 // mapped to the negative error classes and a thread-local message.
 #include <cstring>
+#include <memory>
 #include <string>
 
 #include "generate.hpp"
@@ -51,10 +52,10 @@ int qtts_init(int device_ordinal, qtts_ctx** out) {
     QTTS_HIP(hipGetDeviceProperties(&prop, device_ordinal));
     QTTS_CHECK(std::string(prop.gcnArchName).rfind("gfx950", 0) == 0, ERR_STATE,
                std::string("qtts_init: kernels are built for gfx950 only, found ") + prop.gcnArchName);
-    qtts_ctx* c = new qtts_ctx();
+    std::unique_ptr<qtts_ctx> c(new qtts_ctx());
     c->c.device = device_ordinal;
     QTTS_HIP(hipStreamCreateWithFlags(&c->c.stream, hipStreamNonBlocking));
-    *out = c;
+    *out = c.release();
     QTTS_API_END
 }
 
@@ -210,9 +211,7 @@ int qtts_bench_gemm(qtts_ctx* ctx, int dtype, int M, int N, int K, int KS, int i
     out.alloc((size_t)KS * Mpad * N * 4);
     QTTS_HIP(hipMemsetAsync(W.p, 0x3c, wbytes * copies, ctx->c.stream));
     QTTS_HIP(hipMemsetAsync(X.p, 0x3c, (size_t)Mpad * K * es, ctx->c.stream));
-    hipEvent_t e0, e1;
-    QTTS_HIP(hipEventCreate(&e0));
-    QTTS_HIP(hipEventCreate(&e1));
+    ScopedEvent e0, e1;
     for (int i = 0; i < 3; ++i) launch_gemm(ctx->c.stream, dtype, (char*)W.p + wbytes * (i % copies), X.p, out.as<float>(), M, N, K, KS, K);
     QTTS_HIP(hipEventRecord(e0, ctx->c.stream));
     for (int i = 0; i < iters; ++i) launch_gemm(ctx->c.stream, dtype, (char*)W.p + wbytes * (i % copies), X.p, out.as<float>(), M, N, K, KS, K);
@@ -221,8 +220,6 @@ int qtts_bench_gemm(qtts_ctx* ctx, int dtype, int M, int N, int K, int KS, int i
     float ms = 0;
     QTTS_HIP(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = (double)ms * 1000.0 / iters;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     QTTS_API_END
 }
 
@@ -233,9 +230,7 @@ int qtts_bench_sync(qtts_ctx* ctx, int mode, int blocks, int threads, int iters,
     QTTS_CHECK(ctx && avg_us && errors && iters >= 1, ERR_BAD_ARG, "qtts_bench_sync: bad argument");
     QTTS_HIP(hipSetDevice(ctx->c.device));
     hipStream_t st = ctx->c.stream;
-    hipEvent_t e0, e1;
-    QTTS_HIP(hipEventCreate(&e0));
-    QTTS_HIP(hipEventCreate(&e1));
+    ScopedEvent e0, e1;
     float ms = 0;
     *errors = 0;
     if (mode == 0) {
@@ -308,8 +303,6 @@ int qtts_bench_sync(qtts_ctx* ctx, int mode, int blocks, int threads, int iters,
         (void)hipGraphExecDestroy(exec);
         *avg_us = (double)ms * 1e3 / iters;
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     QTTS_API_END
 }
 
@@ -321,9 +314,7 @@ int qtts_bench_stream(qtts_ctx* ctx, long bytes, int blocks, int pattern, int un
     src.alloc((size_t)bytes * copies);
     sink.alloc(64);
     QTTS_HIP(hipMemsetAsync(src.p, 0x11, (size_t)bytes * copies, ctx->c.stream));
-    hipEvent_t e0, e1;
-    QTTS_HIP(hipEventCreate(&e0));
-    QTTS_HIP(hipEventCreate(&e1));
+    ScopedEvent e0, e1;
     for (int i = 0; i < 3; ++i) launch_stream(ctx->c.stream, (char*)src.p + (size_t)bytes * (i % copies), sink.as<unsigned>(), bytes, blocks, pattern, unroll, ld_bytes);
     QTTS_HIP(hipEventRecord(e0, ctx->c.stream));
     for (int i = 0; i < iters; ++i) launch_stream(ctx->c.stream, (char*)src.p + (size_t)bytes * (i % copies), sink.as<unsigned>(), bytes, blocks, pattern, unroll, ld_bytes);
@@ -332,8 +323,6 @@ int qtts_bench_stream(qtts_ctx* ctx, long bytes, int blocks, int pattern, int un
     float ms = 0;
     QTTS_HIP(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = (double)ms * 1000.0 / iters;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     QTTS_API_END
 }
 

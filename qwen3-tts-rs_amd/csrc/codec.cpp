@@ -360,9 +360,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
     s.acc.ensure(g.acc_elems * 4);
     s.wav.ensure((size_t)U * (size_t)g.wav_max * 4);
 
-    hipEvent_t ev0, ev1;
-    QTTS_HIP(hipEventCreate(&ev0));
-    QTTS_HIP(hipEventCreate(&ev1));
+    ScopedEvent ev0, ev1;
     QTTS_HIP(hipEventRecord(ev0, st));
     // ================= stage 0: RVQ lookup -> pre_conv -> transformer =================
     const long M0 = U * S[0];
@@ -623,8 +621,6 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
     QTTS_HIP(hipEventElapsedTime(&ms, ev0, ev1));
     m.timing[6] += ms;
     if (profiling) report();
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
 }
 
 }  // namespace

@@ -33,6 +33,18 @@ constexpr int ERR_BAD_ARG = -1, ERR_HIP = -2, ERR_OOM = -3, ERR_SHAPE = -4, ERR_
         if (!(cond)) throw ::qtts::Error((code), (msg));     \
     } while (0)
 
+// HIP event owned by a scope: destroyed on every way out, including the exceptions QTTS_HIP / QTTS_CHECK throw.
+struct ScopedEvent {
+    hipEvent_t e = nullptr;
+    ScopedEvent() { QTTS_HIP(hipEventCreate(&e)); }
+    ~ScopedEvent() {
+        if (e) (void)hipEventDestroy(e);
+    }
+    ScopedEvent(const ScopedEvent&) = delete;
+    ScopedEvent& operator=(const ScopedEvent&) = delete;
+    operator hipEvent_t() const { return e; }
+};
+
 inline uint16_t f32_to_bf16(float f) {  // round-to-nearest-even, NaN kept quiet
     uint32_t u;
     __builtin_memcpy(&u, &f, 4);

@@ -300,10 +300,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         QTTS_HIP(hipMemcpy(g.uniforms.p, u.data(), u.size() * 4, hipMemcpyHostToDevice));
     }
 
-    hipEvent_t ev0, ev1, ev2;
-    QTTS_HIP(hipEventCreate(&ev0));
-    QTTS_HIP(hipEventCreate(&ev1));
-    QTTS_HIP(hipEventCreate(&ev2));
+    ScopedEvent ev0, ev1, ev2;
     QTTS_HIP(hipEventRecord(ev0, st));
 
     // ------------------------------------------------------------------ upload descriptors
@@ -643,9 +640,6 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     m.timing[5] = (double)steps_done;
     m.timing[7] = launch_host_ms;
     m.gemm_profile = g.timer.by_shape();
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
-    (void)hipEventDestroy(ev2);
 }
 
 }  // namespace qtts
