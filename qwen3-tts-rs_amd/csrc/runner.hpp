@@ -1,7 +1,9 @@
 // Shared layer runner: one pre-norm transformer layer / stack over M tokens in flight, used by the talker,
 // the code predictor and the codec's sliding-window transformer.
 #pragma once
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "model.hpp"
@@ -57,19 +59,23 @@ struct Runner {
     hipStream_t st;
     int dt;
     size_t es;
-    static constexpr int ROWS_KERNEL_MIN_M = 129;  // above this many tokens the large-M kernel (no split-K slabs) is used
+    // from this many tokens on the large-M kernel (no split-K slabs) is used; the slab workspaces are sized for at most 512 rows
+    static int rows_kernel_min_m() {
+        static const int v = getenv("QTTS_ROWS_MIN_M") ? std::min(513, std::max(17, atoi(getenv("QTTS_ROWS_MIN_M")))) : 513;
+        return v;
+    }
 
     Runner(Model& model, Workspace& ws, GemmTimer* t) : m(model), g(ws), timer(t), st(model.ctx->stream), dt(model.dtype), es(dtype_size(model.dtype)) {}
 
     // split-K factor the consumers of g.part must assume for a GEMM of this shape
     int ks_for(int M, int N, int K) const {
-        if (M >= ROWS_KERNEL_MIN_M && N % 64 == 0) return 1;
+        if (M >= rows_kernel_min_m() && N % 64 == 0) return 1;
         return gemm_pick_ks(M, N, K, dt);
     }
     long kstride(int M, int N) const { return (long)gemm_pad_rows(M) * N; }
 
     void gemm(const void* W, const void* X, int M, int N, int K, int KS, int ldx) {
-        const bool rows = M >= ROWS_KERNEL_MIN_M && N % 64 == 0;
+        const bool rows = M >= rows_kernel_min_m() && N % 64 == 0;
         const bool time = timer && timer->enabled && timer->used + 2 <= 400000;
         if (time) {
             while (timer->ev.size() < timer->used + 2) {
