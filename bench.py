@@ -241,6 +241,13 @@ def main():
                     "note": "achieved = algorithmic bytes of every decode frame in the timed region / wall time of the region "
                             "(includes the overlapped prefill and codec phases); avg_launch_ms is per stream",
                     "weight_bytes_per_launch": synth.weight_bytes_per_frame(cfg, es)["total"]}
+        # the same frames priced against the matrix cores: at 64 rows a weight-streaming GEMM does 64 FLOP per byte, far below the
+        # ridge (~310 FLOP/B), so this is a reported utilisation, not the bound
+        fl_frame = synth.decode_flops_per_frame(cfg, args.batch, avg_ctx)
+        mfma_peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+        mfma_ach = fl_frame * frames_run / elapsed / 1e12
+        roofline["mfma_utilisation"] = {"achieved": round(mfma_ach, 1), "peak": mfma_peak, "unit": "TFLOP/s",
+                                        "frac": round(mfma_ach / mfma_peak, 4), "flops_per_launch": fl_frame}
         # dominant weight-streaming GEMM, timed launch by launch with HIP events in an eager pass after the timed region
         m.generate(reqs, sampling, 9, use_graph=False, profile_gemm=True)
         prof = [p for p in m.gemm_profile() if p["M"] == args.batch]

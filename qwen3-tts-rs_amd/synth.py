@@ -386,6 +386,15 @@ def decode_bytes_per_frame(cfg, batch: int, ctx: float, bytes_per_elem: int = 2)
     return float(w["total"] + batch * (kv_t + kv_c + bytes_per_elem * G * H))
 
 
+def decode_flops_per_frame(cfg, batch: int, ctx: float) -> float:
+    """Algorithmic FLOPs of one decode frame for the whole batch: 2 per weight per row for every projection of the talker,
+    the G-1 code-predictor passes and their heads, plus the talker's attention over `ctx` cached positions."""
+    t = cfg["talker_config"]
+    w = weight_bytes_per_frame(cfg, 1)
+    attn = 4.0 * t["num_hidden_layers"] * t["num_attention_heads"] * t["head_dim"] * ctx
+    return float(batch) * (2.0 * w["total"] + attn)
+
+
 def codec_flops_per_frame(codec_cfg) -> float:
     """Algorithmic FLOPs (2 per multiply-add, GEMM/conv terms only) the codec decoder spends per 12.5 Hz frame."""
     c = codec_cfg["decoder_config"]
