@@ -87,6 +87,21 @@ def test_ragged_batch_is_token_identical_per_utterance(t0_f32, bind):
         assert np.abs(r["logits"] - out.logits[b]).max() < 1e-4
 
 
+@pytest.mark.parametrize("batch", [130, 300])
+def test_wide_batches_stay_token_identical(t0_f32, bind, batch):
+    """More than 128 rows per decode step: the split-K GEMM runs one block per 64-row slice (up to 512 rows).  Rows spread over
+    the slices are compared with the oracle run one utterance at a time."""
+    m, cfg, tmpl = t0_f32
+    from qwen3_tts_rs_amd import synth
+    o, _, _, _ = make_oracle(bind, "T0", "f32", talker=True, codec=False)
+    texts = [synth.synthetic_text_ids(tmpl, 3 + (i * 7) % 23, i) for i in range(batch)]
+    out = m.generate([_req(t, speaker=f"speaker{i % 3}") for i, t in enumerate(texts)], _sampling(GREEDY), 6)
+    for b in (0, 63, 64, 127, 128, batch - 1):
+        s = f"speaker{b % 3}"
+        r = o.generate(texts[b], bind.resolve_codec_prefill(cfg, "english", s), GREEDY, 6, speaker_token=bind.resolve_speaker_token(cfg, s))
+        assert np.array_equal(r["codes"], out.codes[b]), f"row {b}"
+
+
 def test_voice_design_and_xvector_prompts(t0_f32, bind, golden):
     m, cfg, tmpl = t0_f32
     o, _, _, _ = make_oracle(bind, "T0", "f32", talker=True, codec=False)
