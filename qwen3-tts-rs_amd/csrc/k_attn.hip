@@ -228,7 +228,9 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KV
     }
     // The key loop is software-pipelined by hand: a fetch covers NG groups of KPW keys per wave, and the K/V rows (with the
     // page-table entries in front of them) of the next fetch are in flight while the current one goes through the online softmax.
-    constexpr int NG = 2;
+    // One group per fetch keeps the block at 120 VGPRs (four blocks per CU instead of three at two groups): with several
+    // batches in flight the extra resident blocks are worth more than the deeper prefetch.
+    constexpr int NG = 1;
     auto fetch = [&](int base, float(&kf)[NG][8], float(&vf)[NG][8]) {
 #pragma unroll
         for (int n = 0; n < NG; ++n) {
