@@ -386,7 +386,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         const int Nmax = std::max({nqkv, 2 * c.inter, Hd, s.latP});
         s.ws.x.ensure(rp * Hd * 4);
         s.ws.xn.ensure(rp * Hd * es);
-        s.ws.part.ensure((size_t)Nmax * std::max(rp, (size_t)16 * std::min<size_t>(rp, 512)) * 4);
+        s.ws.part.ensure((size_t)Nmax * std::max(rp, (size_t)GEMM_MAX_KS * std::min<size_t>(rp, 512)) * 4);
         s.ws.q.ensure(rp * nq * 4);
         s.ws.attn.ensure(rp * nq * es);
         s.ws.act.ensure(rp * c.inter * es);

@@ -285,7 +285,7 @@ void run_encode_audio(Model& m, const float* audio, const int* n_samples, int B,
         const size_t rp = (size_t)gemm_pad_rows(M) + 64;
         s.ws.x.ensure(rp * ENC_DIM * 4);
         s.ws.xn.ensure(rp * ENC_DIM * es);
-        s.ws.part.ensure((size_t)ENC_MLP * std::max(rp, (size_t)16 * std::min<size_t>(rp, 512)) * 4);
+        s.ws.part.ensure((size_t)ENC_MLP * std::max(rp, (size_t)GEMM_MAX_KS * std::min<size_t>(rp, 512)) * 4);
         s.ws.q.ensure(rp * ENC_DIM * 4);
         s.ws.attn.ensure(rp * ENC_DIM * es);
         s.ws.act.ensure(rp * ENC_MLP * es);

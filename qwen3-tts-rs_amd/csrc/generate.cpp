@@ -233,8 +233,8 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
                                2 * c.cp.inter, V, Vc, H, Ht, Hc});
     g.ws.x.ensure(rows * Wmax * 4);
     g.ws.xn.ensure(rows * Wmax * es);
-    // up to 16 split-K slabs for the small-M kernels (at most 512 rows); the large-M kernel writes one [rows][N] matrix
-    g.ws.part.ensure(std::max(rows, (size_t)16 * std::min<size_t>(rows, 512)) * (size_t)Nmax * 4);
+    // up to GEMM_MAX_KS split-K slabs for the small-M kernels (at most 512 rows); the large-M kernel writes one [rows][N] matrix
+    g.ws.part.ensure(std::max(rows, (size_t)GEMM_MAX_KS * std::min<size_t>(rows, 512)) * (size_t)Nmax * 4);
     g.ws.q.ensure(rows * QD * 4);
     g.ws.attn.ensure(rows * QD * es);
     g.ws.act.ensure(rows * Imax * es);

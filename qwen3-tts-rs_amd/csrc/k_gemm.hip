@@ -388,7 +388,7 @@ GemmPlan gemm_plan(int M, int N, int K, int dtype) {
             if (force_nch && nch != force_nch) continue;
             if (N % (64 * nt) != 0 || nC % nch != 0) continue;
             const int ks = nC / nch;
-            if (ks > 16) continue;
+            if (ks > GEMM_MAX_KS) continue;
             const long blocks = (long)(N / (64 * nt)) * ks * Z;
             if (blocks >= 448) { p = GemmPlan{ks, 1, nt, nch}; return p; }
             if (blocks > best_blocks) { best_blocks = blocks; p = GemmPlan{ks, 1, nt, nch}; }
@@ -399,7 +399,7 @@ GemmPlan gemm_plan(int M, int N, int K, int dtype) {
     const long nblk = (long)(N / 16) * Z;  // blocks at KS = 1 with one 16-row tile each
     int ks = 1;
     // aim for >= ~512 blocks (2 per CU) while every wave keeps at least two chunks
-    while (nblk * ks < 512 && nC / (4 * ks * 2) >= 2 && ks < 16) ks *= 2;
+    while (nblk * ks < 512 && nC / (4 * ks * 2) >= 2 && ks < GEMM_MAX_KS) ks *= 2;
     p.KS = ks;
     p.kind = 0;
     p.NT = (N % 32 == 0 && (long)(N / 32) * ks * Z >= 256) ? 2 : 1;

@@ -25,6 +25,7 @@ struct KVView {
 struct GemmPlan {
     int KS, kind, NT, NCH;  // kind 0: in-block split-K kernel, 1: LDS-shared-X kernel
 };
+constexpr int GEMM_MAX_KS = 16;  // most split-K slabs a plan may ask for; the slab workspaces are sized for it
 int gemm_pad_rows(int M);
 GemmPlan gemm_plan(int M, int N, int K, int dtype);
 int gemm_pick_ks(int M, int N, int K, int dtype);
