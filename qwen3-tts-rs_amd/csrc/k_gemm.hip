@@ -130,15 +130,26 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ 
 template <typename T, int MT, int NT, int NCH>
 __global__ __launch_bounds__(256) void gemm_ldsx_kernel(const T* __restrict__ W, const T* __restrict__ X,
                                                         float* __restrict__ out, int N, int K, int ldx,
-                                                        long out_ks_stride) {
+                                                        long out_ks_stride, int GX, int KS, int Z) {
     using F = Frag<T>;
     constexpr int HALF = 16 / sizeof(T);  // elements per 16-byte half fragment
     __shared__ uint4 xs[NCH * MT * 2 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * (64 * NT) + wave * (16 * NT);
-    const int ks = blockIdx.y;
-    const int row0 = blockIdx.z * (16 * MT);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (Z > 1) {
+        // Several row slices (1-D launch): workgroups go to the 8 XCDs round-robin by linear id, so the Z slices of one weight
+        // tile are given ids 8 apart inside one run of 8 * Z ids - same XCD, same moment - and share the tile through that L2.
+        const int L = blockIdx.x;
+        const int t = (L / (8 * Z)) * 8 + (L & 7);
+        if (t >= GX * KS) return;
+        bz = (L >> 3) % Z;
+        bx = t % GX;
+        by = t / GX;
+    }
+    const int n0 = bx * (64 * NT) + wave * (16 * NT);
+    const int ks = by;
+    const int row0 = bz * (16 * MT);
     const size_t kbeg = (size_t)ks * NCH * F::CHUNK;
 
     // X fragment blocks -> LDS (asynchronous, no VGPRs)
@@ -188,8 +199,16 @@ __global__ __launch_bounds__(256) void gemm_ldsx_kernel(const T* __restrict__ W,
 template <typename T, int MT, int NT, int NCH>
 static void launch_ldsx(hipStream_t st, const T* W, const T* X, float* out, int Mpad, int N, int K, int ldx) {
     const int KS = K / (NCH * Frag<T>::CHUNK);
-    dim3 grid(N / (64 * NT), KS, Mpad / (16 * MT));
-    hipLaunchKernelGGL((gemm_ldsx_kernel<T, MT, NT, NCH>), grid, dim3(256), 0, st, W, X, out, N, K, ldx, (long)Mpad * N);
+    const int GX = N / (64 * NT), Z = Mpad / (16 * MT);
+    static const bool xcd_order = !(getenv("QTTS_GEMM_XCD") && atoi(getenv("QTTS_GEMM_XCD")) == 0);
+    if (Z > 1 && xcd_order) {
+        const int groups = (GX * KS + 7) / 8;
+        hipLaunchKernelGGL((gemm_ldsx_kernel<T, MT, NT, NCH>), dim3(groups * 8 * Z), dim3(256), 0, st, W, X, out, N, K, ldx, (long)Mpad * N,
+                           GX, KS, Z);
+        return;
+    }
+    dim3 grid(GX, KS, Z);
+    hipLaunchKernelGGL((gemm_ldsx_kernel<T, MT, NT, NCH>), grid, dim3(256), 0, st, W, X, out, N, K, ldx, (long)Mpad * N, GX, KS, 1);
 }
 
 template <typename T, int MT>
