@@ -92,3 +92,29 @@ def test_long_form_codec_decode():
         assert snr_db(part[32 * 1920:32 * 1920 + n], ref[:n]) > 28.0
     finally:
         m.close()
+
+
+def test_bench_prints_one_contract_line():
+    """bench.py end to end at a reduced size: one JSON line with the fields the harness reads, the roofline of the decode frame
+    measured in the run and the CPU port timed beside it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "4", "--frames", "30",
+                        "--pipeline", "2", "--cpu-frames", "4"], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().split("\n") if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["higher_is_better"] is True and d["data"] == "synthetic" and "workload" in d["config"] and d["value"] > 0
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert "traffic" in rf and rf["achieved"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
