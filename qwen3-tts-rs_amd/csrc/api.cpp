@@ -1,6 +1,9 @@
 // C ABI of libqtts_hip (declared in include/qtts.h).  Exceptions never cross the boundary: they are
 // mapped to the negative error classes and a thread-local message.
+#include <atomic>
+#include <chrono>
 #include <cstring>
+#include <thread>
 #include <memory>
 #include <string>
 
@@ -223,6 +226,22 @@ int qtts_bench_gemm(qtts_ctx* ctx, int dtype, int M, int N, int K, int KS, int i
     QTTS_API_END
 }
 
+// Callers that run qtts_bench_sync from several host threads at once (one context each) set the number of threads here;
+// every call then waits, graph instantiated, until all of them are ready, so that the timed launches overlap on the GPU.
+static std::atomic<int> g_sync_expected{0}, g_sync_arrived{0};
+void qtts_bench_sync_threads(int n) {
+    g_sync_arrived.store(0);
+    g_sync_expected.store(n);
+}
+static void bench_rendezvous() {
+    const int n = g_sync_expected.load();
+    if (n <= 1) return;
+    const int ticket = g_sync_arrived.fetch_add(1) + 1;
+    const int target = (ticket + n - 1) / n * n;  // calls come in rounds of n
+    const auto t0 = std::chrono::steady_clock::now();
+    while (g_sync_arrived.load() < target && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(20)) std::this_thread::yield();
+}
+
 // mode 0: `iters` iterations of two grid barriers inside one resident grid of `blocks` x `threads`; avg_us is per barrier and
 // *errors counts visibility failures / aborted waits.  mode 1: a hipGraph of `iters` empty kernels; avg_us per kernel node.
 int qtts_bench_sync(qtts_ctx* ctx, int mode, int blocks, int threads, int iters, double* avg_us, int* errors) {
@@ -270,6 +289,7 @@ int qtts_bench_sync(qtts_ctx* ctx, int mode, int blocks, int threads, int iters,
         QTTS_HIP(hipStreamEndCapture(st, &graph));
         QTTS_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         QTTS_HIP(hipGraphDestroy(graph));
+        bench_rendezvous();
         for (int rep = 0; rep < 2; ++rep) {
             QTTS_HIP(hipMemsetAsync(a.p, 0, (size_t)n * 4, st));
             QTTS_HIP(hipEventRecord(e0, st));
@@ -280,7 +300,9 @@ int qtts_bench_sync(qtts_ctx* ctx, int mode, int blocks, int threads, int iters,
         QTTS_HIP(hipEventElapsedTime(&ms, e0, e1));
         (void)hipGraphExecDestroy(exec);
         std::vector<float> h((size_t)n);
-        QTTS_HIP(hipMemcpy(h.data(), (iters & 1) ? b.p : a.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+        QTTS_HIP(hipMemcpyAsync(h.data(), (iters & 1) ? b.p : a.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        QTTS_HIP(hipStreamSynchronize(st));
+        bench_rendezvous();  // nobody starts the next capture while another thread still copies
         int bad = 0;
         for (int i = 0; i < n; ++i) bad += h[(size_t)i] != (float)iters;
         *errors = bad;
@@ -293,6 +315,7 @@ int qtts_bench_sync(qtts_ctx* ctx, int mode, int blocks, int threads, int iters,
         QTTS_HIP(hipStreamEndCapture(st, &graph));
         QTTS_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
         QTTS_HIP(hipGraphDestroy(graph));
+        bench_rendezvous();
         for (int rep = 0; rep < 2; ++rep) {
             QTTS_HIP(hipEventRecord(e0, st));
             QTTS_HIP(hipGraphLaunch(exec, st));
