@@ -118,3 +118,37 @@ def test_bench_prints_one_contract_line():
     assert "traffic" in rf and rf["achieved"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+
+
+def test_headline_configuration_at_full_size():
+    """The benchmark's own workload (1.7B-like shapes, bf16, 64 utterances, 375 frames, seeded sampling, codec decode) through
+    size-independent properties: two runs are identical code for code, the hipGraph replay equals kernel-by-kernel launches, every
+    code is inside its codebook, the waveform has 1920 T - 555 samples in [-1, 1], and the first 25 frames pushed through a
+    streaming session are the head of the whole decode."""
+    from conftest import snr_db
+    from qwen3_tts_rs_amd import GenerationRequest, SamplingConfig, synth
+    m, cfg, ccfg, tmpl = _model("S17", "custom_voice", codec=True)
+    try:
+        B, T = 64, 375
+        reqs = [GenerationRequest(text_ids=synth.synthetic_text_ids(tmpl, 8 + (u * 37 + 11) % 57, u), language="english", speaker="speaker1",
+                                  seed=42 + u) for u in range(B)]
+        a = m.generate(reqs, SamplingConfig(), T, min_new_tokens=T)
+        b = m.generate(reqs, SamplingConfig(), T, min_new_tokens=T)
+        assert a.num_steps == T and a.effective_lengths == [T] * B
+        assert np.array_equal(a.codes, b.codes)
+        c = m.generate(reqs[:8], SamplingConfig(), 40, min_new_tokens=40, use_graph=False)
+        d = m.generate(reqs[:8], SamplingConfig(), 40, min_new_tokens=40)
+        assert np.array_equal(c.codes, d.codes)
+        t = cfg["talker_config"]
+        assert (a.codes[:, :, 0] < t["vocab_size"] - 1024).all() and (a.codes[:, :, 1:] < t["code_predictor_config"]["vocab_size"]).all()
+        wavs = m.decode_output(a)
+        for w in wavs:
+            assert len(w) == 1920 * T - 555 and np.isfinite(w).all() and np.abs(w).max() <= 1.0
+        Q = ccfg["decoder_config"]["num_quantizers"]
+        with m.open_codec_stream(B, 25) as s:
+            head = s.push(a.codes[:, :25, :Q])
+        assert head.shape == (B, 1920 * 25 - 555)
+        for u in (0, 31, 63):
+            assert snr_db(wavs[u][:head.shape[1]], head[u]) > 28.0, u
+    finally:
+        m.close()
