@@ -1,5 +1,5 @@
-"""The benchmark configurations that are not the headline run, at their real shapes and batch sizes with shortened
-generation lengths.  The CPU oracle cannot reach these sizes in seconds, so each case checks properties of the algorithm:
+"""The benchmark configurations at their real shapes and batch sizes (the headline run at full length, the others with
+shortened generation lengths).  The CPU oracle cannot reach these sizes in seconds, so each case checks properties of the algorithm:
 determinism, batch-composition independence, length arithmetic, value ranges."""
 import numpy as np
 import pytest
