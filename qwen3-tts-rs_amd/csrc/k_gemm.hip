@@ -392,6 +392,9 @@ GemmPlan gemm_plan(int M, int N, int K, int dtype) {
     static const int force_kind = getenv("QTTS_GEMM_KIND") ? atoi(getenv("QTTS_GEMM_KIND")) : -1;
     static const int force_nt = getenv("QTTS_GEMM_NT") ? atoi(getenv("QTTS_GEMM_NT")) : 0;
     static const int force_nch = getenv("QTTS_GEMM_NCH") ? atoi(getenv("QTTS_GEMM_NCH")) : 0;
+    // first candidate (fewest slabs first) that still gives this many blocks: 192 measured best (fewer slab bytes to write and
+    // read back; with several batches in flight the other streams fill the CUs a smaller grid leaves idle)
+    static const int min_blocks = getenv("QTTS_GEMM_MIN_BLOCKS") ? atoi(getenv("QTTS_GEMM_MIN_BLOCKS")) : 192;
     const int chunk = dtype == BF16 ? 64 : 32;
     const int nC = K / chunk;
     const int Mpad = gemm_pad_rows(M);
@@ -409,7 +412,7 @@ GemmPlan gemm_plan(int M, int N, int K, int dtype) {
             const int ks = nC / nch;
             if (ks > GEMM_MAX_KS) continue;
             const long blocks = (long)(N / (64 * nt)) * ks * Z;
-            if (blocks >= 448) { p = GemmPlan{ks, 1, nt, nch}; return p; }
+            if (blocks >= min_blocks) { p = GemmPlan{ks, 1, nt, nch}; return p; }
             if (blocks > best_blocks) { best_blocks = blocks; p = GemmPlan{ks, 1, nt, nch}; }
         }
         if (best_blocks >= 128 || force_kind == 1) { if (p.kind == 1) return p; }
