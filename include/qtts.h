@@ -78,17 +78,22 @@ typedef struct {
     uint64_t seed;                 /* MT19937 seed of this utterance's draw stream (nn/mt_rng.rs:196) */
 } qtts_request;
 
-/* SamplingConfig (nn/sampling.rs:13-64) as merged by GenerateConfig::merge (model/config.rs:128-157). */
+/* SamplingConfig (nn/sampling.rs:13-64) as merged by GenerateConfig::merge (model/config.rs:128-157).  The floating
+ * point fields are f64 as in the reference and are narrowed exactly where it narrows them: (1 / temperature) as f32
+ * (nn/sampling.rs:199-204), top_p as f32, repetition_penalty as f32.  min_new_tokens: frames during which EOS stays
+ * suppressed (nn/sampling.rs:28-29,55: the reference's default is 2; 0 lets a row end on its first frame, and when every
+ * row does, num_steps is 0 as in nn/generation.rs:939,1145-1150). */
 typedef struct {
-    float temperature;
+    double temperature;
     int top_k;
-    float top_p;
+    double top_p;
     int do_sample;
-    float repetition_penalty;
+    double repetition_penalty;
     int subtalker_do_sample;
-    float subtalker_temperature;
+    double subtalker_temperature;
     int subtalker_top_k;
-    float subtalker_top_p;
+    double subtalker_top_p;
+    int min_new_tokens;
 } qtts_sampling;
 
 /* Output{codes, num_steps, effective_lengths} (nn/generation.rs:31-38) for one utterance.
@@ -114,9 +119,8 @@ typedef struct {
     int first_frames;
     void (*chunk_cb)(void* user, const uint32_t* codes, int n, int frames);
     void* chunk_user;
-    /* Throughput-measurement protocol (no counterpart in the reference): EOS stays suppressed until this many frames exist,
-     * so that every row of a benchmark run produces the same fixed length.  0 = the reference's min_new_tokens = 2
-     * (nn/sampling.rs:55 via nn/generation.rs:841-842). */
+    /* Throughput-measurement protocol (no counterpart in the reference): when > 0, overrides qtts_sampling.min_new_tokens so
+     * that every row of a benchmark run produces the same fixed length. */
     int min_new_tokens;
 } qtts_gen_debug;
 

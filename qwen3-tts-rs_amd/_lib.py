@@ -28,9 +28,10 @@ class Request(C.Structure):
 
 
 class Sampling(C.Structure):
-    _fields_ = [("temperature", C.c_float), ("top_k", C.c_int), ("top_p", C.c_float), ("do_sample", C.c_int),
-                ("repetition_penalty", C.c_float), ("subtalker_do_sample", C.c_int),
-                ("subtalker_temperature", C.c_float), ("subtalker_top_k", C.c_int), ("subtalker_top_p", C.c_float)]
+    _fields_ = [("temperature", C.c_double), ("top_k", C.c_int), ("top_p", C.c_double), ("do_sample", C.c_int),
+                ("repetition_penalty", C.c_double), ("subtalker_do_sample", C.c_int),
+                ("subtalker_temperature", C.c_double), ("subtalker_top_k", C.c_int), ("subtalker_top_p", C.c_double),
+                ("min_new_tokens", C.c_int)]
 
 
 class CodesOut(C.Structure):

@@ -38,6 +38,10 @@ int fail(const std::exception& e, int code) {
     }                                                 \
     catch (const std::exception& e) {                 \
         return fail(e, ERR_STATE);                    \
+    }                                                 \
+    catch (...) {                                     \
+        g_err = "unknown exception";                  \
+        return ERR_STATE;                             \
     }
 
 extern "C" {

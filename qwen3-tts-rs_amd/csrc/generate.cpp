@@ -122,8 +122,10 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     for (int b = 0; b < B; ++b) {
         const qtts_request& r = reqs[b];
         QTTS_CHECK(r.text_ids && r.n_text >= 4, ERR_BAD_ARG, "generate: text_ids needs at least 4 tokens");
-        const bool icl = r.ref_codes != nullptr && r.ref_T > 0 && r.ref_text_ids != nullptr && r.n_ref_text >= 4;
+        const bool icl = r.ref_codes != nullptr && r.ref_T > 0 && r.ref_text_ids != nullptr && r.n_ref_text > 0;
         QTTS_CHECK(r.ref_T >= 0 && (r.ref_codes == nullptr) == (r.ref_T == 0), ERR_BAD_ARG, "generate: ref_codes and ref_T disagree");
+        // the reference slices ref_text_ids[3..-2] and fails on a shorter transcript (generation.rs:629-640)
+        QTTS_CHECK(!icl || r.n_ref_text >= 4, ERR_BAD_ARG, "generate: ICL reference text needs at least 4 tokens");
         // build_codec_prefill (generation.rs:452-498)
         std::string lang = lower(r.language ? r.language : "auto");
         const std::string spk = lower(r.speaker);
@@ -408,14 +410,15 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         const double T = talker ? sp->temperature : sp->subtalker_temperature;
         a.temperature = T == 1.0 ? 1.0f : (float)(1.0 / T);
         a.top_k = talker ? sp->top_k : sp->subtalker_top_k;
-        a.top_p = talker ? sp->top_p : sp->subtalker_top_p;
+        a.top_p = (float)(talker ? sp->top_p : sp->subtalker_top_p);
         a.do_sample = talker ? sp->do_sample : sp->subtalker_do_sample;
-        a.rep_penalty = talker ? sp->repetition_penalty : 1.0f;
-        a.hist_count = talker && sp->repetition_penalty != 1.0f ? g.hist.as<int>() : nullptr;
+        a.rep_penalty = talker ? (float)sp->repetition_penalty : 1.0f;
+        a.hist_count = talker && sp->repetition_penalty != 1.0 ? g.hist.as<int>() : nullptr;
         a.suppress_lo = talker ? std::max(0, V - 1024) : 0;
         a.suppress_hi = talker ? V : 0;
         a.eos_id = talker ? c.eos : -1;
-        a.min_new_tokens = talker ? (dbg && dbg->min_new_tokens > 0 ? dbg->min_new_tokens : 2) : 0;  // sampling.rs:55 via generation.rs:841-842; subtalker: sampling.rs:117
+        // sampling.rs:28-29 via generation.rs:841-842; subtalker: sampling.rs:117
+        a.min_new_tokens = talker ? (dbg && dbg->min_new_tokens > 0 ? dbg->min_new_tokens : std::max(0, sp->min_new_tokens)) : 0;
         a.step = d_step; a.uniforms = g.uniforms.as<float>(); a.codes_base = g.codes.as<unsigned>(); a.row_stride = row_stride;
         a.G = G; a.g = gcol; a.eos_step = talker ? g.eos_step.as<int>() : nullptr;
         launch_sample(st, a);
@@ -619,7 +622,8 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         if (eos[(size_t)b] < 0 || eos[(size_t)b] >= steps_done) { every = false; eos[(size_t)b] = -1; }
         else last_eos = std::max(last_eos, eos[(size_t)b]);
     }
-    const int num_steps = every ? std::min(steps_done, last_eos + 1) : steps_done;
+    // every row ended on its very first token: the reference returns no frame at all (generation.rs:939,1145-1150)
+    const int num_steps = every ? (last_eos == 0 ? 0 : std::min(steps_done, last_eos + 1)) : steps_done;
     std::vector<uint32_t> hcodes((size_t)B * max_new * G);
     QTTS_HIP(hipMemcpy(hcodes.data(), g.codes.p, hcodes.size() * 4, hipMemcpyDeviceToHost));
     for (int b = 0; b < B; ++b) {

@@ -70,6 +70,7 @@ class SamplingConfig:  # nn/sampling.rs:13-64 (suppress list / eos / min_new_tok
     subtalker_temperature: float = 0.9
     subtalker_top_k: int = 50
     subtalker_top_p: float = 1.0
+    min_new_tokens: int = 2      # nn/sampling.rs:28-29,55
 
     @classmethod
     def cli_greedy(cls) -> "SamplingConfig":
@@ -83,7 +84,7 @@ class SamplingConfig:  # nn/sampling.rs:13-64 (suppress list / eos / min_new_tok
     def to_c(self) -> _lib.Sampling:
         return _lib.Sampling(self.temperature, self.top_k, self.top_p, int(self.do_sample), self.repetition_penalty,
                              int(self.subtalker_do_sample), self.subtalker_temperature, self.subtalker_top_k,
-                             self.subtalker_top_p)
+                             self.subtalker_top_p, int(self.min_new_tokens))
 
 
 @dataclass

@@ -29,6 +29,39 @@ def test_library_exports_every_declared_symbol():
     assert set(_lib.EXPORTS) <= set(names)
 
 
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """Size and every field offset of the ctypes mirrors equal what a C compiler lays out from include/qtts.h."""
+    import subprocess
+    from qwen3_tts_rs_amd import _lib
+    structs = {"qtts_request": _lib.Request, "qtts_sampling": _lib.Sampling, "qtts_codes_out": _lib.CodesOut,
+               "qtts_gen_debug": _lib.GenDebug}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "qtts.h"', 'int main(void) {']
+    for cname, st in structs.items():
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in st._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = {}
+    for ln in subprocess.check_output([str(exe)], text=True).split("\n"):
+        if ln:
+            c, f, v = ln.split()
+            got[(c, f)] = int(v)
+    for cname, st in structs.items():
+        assert got[(cname, "size")] == C.sizeof(st), cname
+        for fname, _ in st._fields_:
+            assert got[(cname, fname)] == getattr(st, fname).offset, f"{cname}.{fname}"
+    # every field of the header's structs is mirrored (a field added to the header alone would shift nothing but be lost)
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "qtts.h")).read(), flags=re.S)
+    for cname, st in structs.items():
+        body = re.search(r"typedef struct \{([^}]*)\}\s*" + cname + ";", hdr).group(1)
+        n_fields = len([d for d in body.split(";") if d.strip()])
+        assert n_fields == len(st._fields_), cname
+
+
 def test_header_cites_the_reference_for_every_entry_point():
     hdr = open(os.path.join(ROOT, "include", "qtts.h")).read()
     assert hdr.count(".rs:") >= 10

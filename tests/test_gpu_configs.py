@@ -1,6 +1,7 @@
 """The benchmark configurations at their real shapes and batch sizes (the headline run at full length, the others with
-shortened generation lengths).  The CPU oracle cannot reach these sizes in seconds, so each case checks properties of the algorithm:
-determinism, batch-composition independence, length arithmetic, value ranges."""
+shortened generation lengths) through size-independent properties of the algorithm: determinism, batch-composition
+independence (per-row logit bounds), length arithmetic, value ranges.  The comparisons with the CPU oracle at these shapes
+are in test_gpu_parity_full_size.py."""
 import numpy as np
 import pytest
 
@@ -8,6 +9,16 @@ from conftest import SEED
 from golden.make_golden import GREEDY, test_audio as make_audio
 
 pytestmark = pytest.mark.gpu
+
+BF16_LOGIT_TOL = 2e-2
+
+
+def _logits_agree_while_histories_do(codes_a, logits_a, codes_b, logits_b):
+    """max-abs logit difference of one utterance between two runs, over the frames whose code histories are equal."""
+    same = (codes_a == codes_b).all(axis=1)
+    n = len(same)
+    upto = min((int(np.argmin(same)) if not same.all() else n) + 1, n)
+    return float(np.abs(logits_a[:upto] - logits_b[:upto]).max())
 
 
 def _model(shape, model_type, talker=True, codec=False, speaker=False, dtype="bf16"):
@@ -25,7 +36,7 @@ def _model(shape, model_type, talker=True, codec=False, speaker=False, dtype="bf
 
 def _greedy():
     from qwen3_tts_rs_amd import SamplingConfig
-    return SamplingConfig(**{k: GREEDY[k] for k in SamplingConfig().__dict__})
+    return SamplingConfig(**{k: GREEDY[k] for k in SamplingConfig().__dict__ if k in GREEDY})
 
 
 def test_small_model_batch_one_decode_and_codec():
@@ -41,11 +52,12 @@ def test_small_model_batch_one_decode_and_codec():
         assert np.array_equal(a.codes, b.codes) and a.num_steps == 40
         wav = m.decode_output(a)[0]
         assert len(wav) == 1920 * a.effective_lengths[0] - 555 and np.isfinite(wav).all() and np.abs(wav).max() <= 1.0
-        # the same utterance inside a batch of other utterances produces the same codes up to bf16 near-ties of the
-        # batched GEMM path: the first frame's first codebook is decided by the prefill alone and must agree
+        # the same utterance inside a batch of other utterances: its logits stay within the bf16 tolerance for as long as
+        # the code histories agree (the batched GEMM path sums in another order)
         others = [GenerationRequest(text_ids=synth.synthetic_text_ids(tmpl, 9 + i, 10 + i), language="english", speaker_embed=xvec) for i in range(3)]
-        c = m.generate([req] + others, _greedy(), 4)
-        assert c.codes[0, 0, 0] == a.codes[0, 0, 0]
+        a4 = m.generate([req], _greedy(), 4, trace=True)
+        c = m.generate([req] + others, _greedy(), 4, trace=True)
+        assert _logits_agree_while_histories_do(a4.codes[0], a4.logits[0], c.codes[0], c.logits[0]) <= BF16_LOGIT_TOL
     finally:
         m.close()
 
@@ -63,12 +75,14 @@ def test_voice_clone_batch_256():
         assert np.abs(again - emb[:7]).max() <= 2e-2 * np.abs(emb[:7]).max()
         reqs = [GenerationRequest(text_ids=synth.synthetic_text_ids(tmpl, 8 + i % 40, i), language="english", speaker_embed=emb[i])
                 for i in range(n)]
-        out = m.generate(reqs, _greedy(), 3)
+        out = m.generate(reqs, _greedy(), 3, trace=True)
         assert out.codes.shape == (n, 3, cfg["talker_config"]["num_code_groups"])
         t = cfg["talker_config"]
         assert (out.codes[:, :, 0] < t["vocab_size"]).all() and (out.codes[:, :, 1:] < t["code_predictor_config"]["vocab_size"]).all()
-        sub = m.generate(reqs[64:128], _greedy(), 3)     # rows do not depend on their batch
-        assert (sub.codes[:, 0, 0] == out.codes[64:128, 0, 0]).mean() > 0.9
+        sub = m.generate(reqs[64:128], _greedy(), 3, trace=True)     # rows do not depend on their batch
+        for i in range(64):
+            d = _logits_agree_while_histories_do(sub.codes[i], sub.logits[i], out.codes[64 + i], out.logits[64 + i])
+            assert d <= BF16_LOGIT_TOL, f"row {64 + i}: {d:.4f}"
     finally:
         m.close()
 

@@ -31,7 +31,7 @@ def _pair(bind, mutate=None, shape="T0"):
 
 def _check(bind, m, o, cfg, texts, sampling, steps, seeds=None, **okw):
     from qwen3_tts_rs_amd import GenerationRequest, SamplingConfig
-    sc = SamplingConfig(**{k: sampling[k] for k in SamplingConfig().__dict__})
+    sc = SamplingConfig(**{k: sampling[k] for k in SamplingConfig().__dict__ if k in sampling})
     reqs = [GenerationRequest(text_ids=t, language="english", speaker="speaker1", seed=None if seeds is None else seeds[i])
             for i, t in enumerate(texts)]
     out = m.generate(reqs, sc, steps)

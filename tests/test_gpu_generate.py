@@ -13,7 +13,7 @@ BF16_LOGIT_TOL = 2e-2
 
 def _sampling(d):
     from qwen3_tts_rs_amd import SamplingConfig
-    return SamplingConfig(**{k: d[k] for k in SamplingConfig().__dict__})
+    return SamplingConfig(**{k: d[k] for k in SamplingConfig().__dict__ if k in d})
 
 
 @pytest.fixture(scope="module")

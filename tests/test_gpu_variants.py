@@ -19,7 +19,7 @@ from golden.make_golden import GREEDY, SAMPLED
 from qwen3_tts_rs_amd import GenerationRequest, SamplingConfig, synthetic_model
 g = np.load(os.path.join(ROOT, "tests", "golden", "t0_golden.npz"))
 m, cfg, ccfg, tmpl = synthetic_model("T0", dtype="f32", codec=True)
-samp = lambda d: SamplingConfig(**{k: d[k] for k in SamplingConfig().__dict__})
+samp = lambda d: SamplingConfig(**{k: d[k] for k in SamplingConfig().__dict__ if k in d})
 req = GenerationRequest(text_ids=g["text_ids"], language="english", speaker="speaker1")
 out = m.generate([req], samp(GREEDY), 64)
 assert np.array_equal(out.codes[0], g["greedy_codes"]), "greedy tokens differ"
