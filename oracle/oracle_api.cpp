@@ -342,6 +342,7 @@ void orc_attention_mask_from_lengths(const int* lengths, int n, int max_len, flo
             }
     }
 }
+void orc_set_round_probe(int mask) { set_round_probe(mask); }
 void orc_linear(const float* x, const float* w, const float* b, float* y, int64_t M, int64_t N, int64_t K) { linear(x, w, b, y, M, N, K); }
 void orc_rmsnorm(const float* x, const float* w, float* y, int64_t rows, int64_t n, float eps) { rmsnorm(x, w, y, rows, n, eps); }
 

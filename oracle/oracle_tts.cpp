@@ -208,11 +208,27 @@ void RopeTable::cos_sin(int64_t pos, float* c, float* s) const {
 }
 
 // -------------------------------------------------------------------------- decoder layer
+// Diagnostic only (0 in every parity check): rounds the named intermediate tensors to bf16 so that the storage precision of
+// a reduced-precision implementation can be priced tensor by tensor.  bit 0: normed layer inputs, bit 1: keys / values,
+// bit 2: attention output, bit 3: MLP activation.
+static int g_round_probe = 0;
+void set_round_probe(int mask) { g_round_probe = mask; }
+static void probe_round(float* x, size_t n, int bit) {
+    if (!(g_round_probe & (1 << bit))) return;
+    for (size_t i = 0; i < n; ++i) {
+        uint32_t u;
+        std::memcpy(&u, &x[i], 4);
+        u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;
+        std::memcpy(&x[i], &u, 4);
+    }
+}
+
 void decoder_layer(const Weights& w, const std::string& p, const AttnShape& a, const RopeTable& rope, float* x,
                    int T, int pos0, MaskMode mask, KVCacheLayer& cache) {
     const int H = a.hidden, nh = a.nh, nkv = a.nkv, d = a.d, half = d / 2;
     std::vector<float> xn((size_t)T * H), q((size_t)T * nh * d), k((size_t)T * nkv * d), v((size_t)T * nkv * d);
     rmsnorm(x, W(w, p + "input_layernorm.weight").p(), xn.data(), T, H, a.eps);
+    probe_round(xn.data(), xn.size(), 0);
     auto bias = [&](const char* n) -> const float* {
         std::string key = p + "self_attn." + n + ".bias";
         return (a.bias && has(w, key)) ? W(w, key).p() : nullptr;
@@ -237,6 +253,8 @@ void decoder_layer(const Weights& w, const std::string& p, const AttnShape& a, c
         for (int h = 0; h < nh; ++h) rot(&q[((size_t)t * nh + h) * d]);
         for (int h = 0; h < nkv; ++h) rot(&k[((size_t)t * nkv + h) * d]);
     }
+    probe_round(k.data(), k.size(), 1);
+    probe_round(v.data(), v.size(), 1);
     // KV append (kv_cache.rs:38-42)
     if (cache.len + T > cache.cap) throw std::runtime_error("oracle: kv cache overflow");
     for (int t = 0; t < T; ++t)
@@ -273,16 +291,19 @@ void decoder_layer(const Weights& w, const std::string& p, const AttnShape& a, c
         }
     }
     cache.len = kv_len;
+    probe_round(attn.data(), attn.size(), 2);
     std::vector<float> o((size_t)T * H);
     linear(attn.data(), W(w, p + "self_attn.o_proj.weight").p(), bias("o_proj"), o.data(), T, H, nh * d);
     for (size_t i = 0; i < (size_t)T * H; ++i) x[i] = x[i] + o[i];
     // MLP (mlp.rs:59-82): down(silu(gate) * up)
     rmsnorm(x, W(w, p + "post_attention_layernorm.weight").p(), xn.data(), T, H, a.eps);
+    probe_round(xn.data(), xn.size(), 0);
     const int I = a.inter;
     std::vector<float> g((size_t)T * I), u((size_t)T * I);
     linear(xn.data(), W(w, p + "mlp.gate_proj.weight").p(), nullptr, g.data(), T, I, H);
     linear(xn.data(), W(w, p + "mlp.up_proj.weight").p(), nullptr, u.data(), T, I, H);
     for (size_t i = 0; i < (size_t)T * I; ++i) g[i] = silu(g[i]) * u[i];
+    probe_round(g.data(), g.size(), 3);
     linear(g.data(), W(w, p + "mlp.down_proj.weight").p(), nullptr, o.data(), T, H, I);
     for (size_t i = 0; i < (size_t)T * H; ++i) x[i] = x[i] + o[i];
 }

@@ -385,11 +385,9 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         const int nqkv = (c.heads + 2 * c.kv_heads) * c.head_dim, nq = c.heads * c.head_dim;
         const int Nmax = std::max({nqkv, 2 * c.inter, Hd, s.latP});
         s.ws.x.ensure(rp * Hd * 4);
-        s.ws.xn.ensure(rp * Hd * es);
+        s.ws.alloc_inputs(rp, (size_t)Hd, (size_t)nq, (size_t)c.inter, es, split_activations(dt));
         s.ws.part.ensure((size_t)Nmax * std::max(rp, (size_t)GEMM_MAX_KS * std::min<size_t>(rp, 512)) * 4);
         s.ws.q.ensure(rp * nq * 4);
-        s.ws.attn.ensure(rp * nq * es);
-        s.ws.act.ensure(rp * c.inter * es);
         // pages: one private range per strip + one shared dump page for the padding rows
         const int pp = sc ? sc->ring_pages : (Tm + PAGE - 1) / PAGE;
         // a streaming push holds C context frames in front of the new ones: only the new frames are tokens, at the
@@ -437,11 +435,11 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         int ks = run.ks_for(M, Hd, s.latP);
         run.gemm(s.in_proj.w.p, s.Bf.p, M, Hd, s.latP, ks, s.latP);
         launch_resid_norm(st, dt, nullptr, s.ws.part.as<float>(), ks, run.kstride(M, Hd), s.in_proj.bias.as<float>(), nullptr,
-                          s.xf.layers[0].ln1, c.eps, s.ws.x.as<float>(), s.ws.xn.p, nullptr, M, Hd);
-        run.stack(s.xf, M, s.toks.as<Tok>(), kv, s.ws.xn.p, nullptr, sc != nullptr);
+                          s.xf.layers[0].ln1, c.eps, s.ws.x.as<float>(), s.ws.xn.p, nullptr, M, Hd, s.ws.lo_xn);
+        run.stack(s.xf, M, s.toks.as<Tok>(), kv, s.ws.xn.p, nullptr, sc != nullptr, false, s.ws.lo_xn);
         // output_proj (+bias) -> strips without padding (the next op is a kernel == stride transposed conv)
         ks = run.ks_for(M, s.latP, Hd);
-        run.gemm(s.out_proj.w.p, s.ws.xn.p, M, s.latP, Hd, ks, Hd);
+        run.gemm(s.out_proj.w.p, s.ws.xn.p, M, s.latP, Hd, ks, Hd, s.ws.lo_xn);
         const float* acc = s.ws.part.as<float>();
         if (ks != 1) {  // fold the split-K slabs so that the conv epilogue sees one [M][N] matrix
             launch_bias_act(st, s.ws.part.as<float>(), ks, run.kstride(M, s.latP), nullptr, 0, s.acc.p, F32, M, s.latP);

@@ -58,6 +58,30 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
     *reinterpret_cast<uint4*>(p) = o;
 }
 
+// Split activations.  A model-dtype activation tensor that feeds a GEMM may carry a second plane, `lo` elements behind the
+// first, holding the rounding remainder T(v - f32(T(v))).  A GEMM that multiplies both planes sees v to about 16
+// significant bits instead of bf16's 8, at bf16 MFMA rate (weights stay plain bf16).  lo == 0: single plane (always for f32).
+template <typename T>
+__device__ __forceinline__ void store_split(T* p, long lo, float v) {
+    const T h = from_f32<T>(v);
+    p[0] = h;
+    if (lo) p[lo] = from_f32<T>(v - to_f32<T>(h));
+}
+template <typename T>
+__device__ __forceinline__ void store8_split(T* p, long lo, const float (&v)[8]);
+template <>
+__device__ __forceinline__ void store8_split<float>(float* p, long, const float (&v)[8]) { store8(p, v); }
+template <>
+__device__ __forceinline__ void store8_split<bf16_t>(bf16_t* p, long lo, const float (&v)[8]) {
+    store8(p, v);
+    if (lo) {
+        float r[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = v[e] - bf16_bits_to_f32(f32_to_bf16_bits(v[e]));
+        store8(p + lo, r);
+    }
+}
+
 // Sum of KS split-K partial slabs (element p[k * stride]) in slab order, with the loads of up to four slabs in flight
 // at once (a plain loop serialises one memory round trip per slab).  The add order is the same as the plain loop's.
 __device__ __forceinline__ float4 slab_sum4(const float* p, int KS, long stride) {

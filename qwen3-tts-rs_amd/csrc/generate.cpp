@@ -97,10 +97,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     const int dt = m.dtype;
     const size_t es = R.es;
     const bool use_graph = dbg ? dbg->use_graph != 0 : true;
-    // Experimental decode schedule with epilogue-fused GEMMs (k_gemm_fused.hip): 5 launches per layer instead of 8, token-exact,
-    // but its one-block-per-tile GEMM is slower at 64 rows than the split-K kernels, so it is opt-in (QTTS_FUSED=1).
-    static const bool fused_env = getenv("QTTS_FUSED") && atoi(getenv("QTTS_FUSED")) != 0;
-    const bool fused = fused_env && 2 * n <= 256;
+    const bool split = split_activations(dt);
     g.timer.enabled = dbg && dbg->profile_gemm && !use_graph;
     g.timer.used = 0;
     g.timer.bytes = 0;
@@ -234,22 +231,16 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     const int Nmax = std::max({(c.talker.nh + 2 * c.talker.nkv) * c.talker.d, (c.cp.nh + 2 * c.cp.nkv) * c.cp.d, 2 * c.talker.inter,
                                2 * c.cp.inter, V, Vc, H, Ht, Hc});
     g.ws.x.ensure(rows * Wmax * 4);
-    g.ws.xn.ensure(rows * Wmax * es);
+    g.ws.alloc_inputs(rows, (size_t)Wmax, (size_t)QD, (size_t)Imax, es, split);
     // up to GEMM_MAX_KS split-K slabs for the small-M kernels (at most 512 rows); the large-M kernel writes one [rows][N] matrix
     g.ws.part.ensure(std::max(rows, (size_t)GEMM_MAX_KS * std::min<size_t>(rows, 512)) * (size_t)Nmax * 4);
     g.ws.q.ensure(rows * QD * 4);
-    g.ws.attn.ensure(rows * QD * es);
-    g.ws.act.ensure(rows * Imax * es);
-    if (fused) {
-        g.ws.out.ensure(rows * (size_t)Nmax * 4);
-        g.ws.xb.ensure(rows * Wmax * es);
-        g.ws.ss_ld = (long)rows;
-        const size_t max_tiles = (size_t)Wmax / 16 + 1;
-        g.ws.ssA.ensure(max_tiles * rows * 4);
-        g.ws.ssB.ensure(max_tiles * rows * 4);
-    }
     const size_t cp_rows = (size_t)gemm_pad_rows(2 * B) + 64;
-    g.cp_in_t.ensure(cp_rows * H * es);
+    // code-predictor input rows: [0, B) the talker's post-norm hidden (split like every GEMM input of a bf16 run), [B, 2B)
+    // embedding rows copied from the table (exact in the table's dtype: their remainder plane stays zero)
+    g.cp_in_t.ensure(cp_rows * H * es * (split ? 2 : 1));
+    const long lo_cp = split ? (long)(cp_rows * H) : 0;
+    if (split) QTTS_HIP(hipMemsetAsync((char*)g.cp_in_t.p + (size_t)lo_cp * es, 0, cp_rows * H * es, st));
     g.cp_in_f.ensure(cp_rows * H * 4);
     g.text_rows.ensure((size_t)Nt * H * 4);
     g.extra.ensure(std::max<size_t>(extra_rows.size(), 1) * 4);
@@ -355,9 +346,9 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         launch_gather_rows(st, m.text_emb, dt, d_textids + o, g.ws.xn.p, dt, M, Ht, Ht);
         int ks = R.ks_for(M, Ht, Ht);
         R.gemm(m.fc1, g.ws.xn.p, M, Ht, Ht, ks, Ht);
-        launch_bias_act(st, g.ws.part.as<float>(), ks, R.kstride(M, Ht), m.fc1_b, 1, g.ws.act.p, dt, M, Ht);
+        launch_bias_act(st, g.ws.part.as<float>(), ks, R.kstride(M, Ht), m.fc1_b, 1, g.ws.act.p, dt, M, Ht, g.ws.lo_act);
         ks = R.ks_for(M, H, Ht);
-        R.gemm(m.fc2, g.ws.act.p, M, H, Ht, ks, Ht);
+        R.gemm(m.fc2, g.ws.act.p, M, H, Ht, ks, Ht, g.ws.lo_act);
         launch_bias_act(st, g.ws.part.as<float>(), ks, R.kstride(M, H), m.fc2_b, 0, g.text_rows.as<float>() + (size_t)o * H, F32, M, H);
     }
     launch_gather_rows(st, g.text_rows.p, F32, d_trail, g.trailing.p, F32, B * Tt_max, H, H);
@@ -376,9 +367,9 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
             launch_assemble(st, g.text_rows.as<float>(), d_ptext + o, m.codec_emb, dt, d_pcodec + o, g.extra.as<float>(),
                             d_pextra + o, g.ws.x.as<float>(), M, H);
             launch_resid_norm(st, dt, g.ws.x.as<float>(), nullptr, 0, 0, nullptr, nullptr, m.talker.layers[0].ln1, c.talker.eps, g.ws.x.as<float>(),
-                              g.ws.xn.p, nullptr, M, H);
+                              g.ws.xn.p, nullptr, M, H, g.ws.lo_xn);
             // final norm output reuses act (T) and q (f32) as scratch rows
-            R.stack(m.talker, M, g.toks_prompt.as<Tok>() + o, g.talker.kv, g.ws.act.p, g.ws.q.as<float>());
+            R.stack(m.talker, M, g.toks_prompt.as<Tok>() + o, g.talker.kv, g.ws.act.p, g.ws.q.as<float>(), true, false, g.ws.lo_act);
             last_src.clear();
             last_dst.clear();
             for (int b = 0; b < B; ++b)
@@ -388,6 +379,8 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
                 QTTS_HIP(hipMemcpyAsync(d_last_src, last_src.data(), (size_t)nl * 4, hipMemcpyHostToDevice, st));
                 QTTS_HIP(hipMemcpyAsync(d_last_dst, last_dst.data(), (size_t)nl * 4, hipMemcpyHostToDevice, st));
                 launch_copy_rows(st, g.ws.act.p, d_last_src, hid_t, d_last_dst, dt, nl, H);
+                if (split)
+                    launch_copy_rows(st, (char*)g.ws.act.p + (size_t)g.ws.lo_act * es, d_last_src, (char*)hid_t + (size_t)lo_cp * es, d_last_dst, dt, nl, H);
                 launch_copy_rows(st, g.ws.q.p, d_last_src, hid_f, d_last_dst, F32, nl, H);
                 QTTS_HIP(hipStreamSynchronize(st));  // last_src/last_dst are reused by the next chunk
             }
@@ -425,72 +418,9 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     };
 
     // logits -> cb0 -> code predictor -> next talker input (generation.rs:1029-1106)
-    // fused path: every GEMM carries its consumer's element-wise work (k_gemm_fused.hip)
-    auto frame_tail_fused = [&]() {
-        float* ssA = g.ws.ssA.as<float>();
-        GemmEpi eh{};
-        eh.mode = GEMM_EPI_PLAIN; eh.out_f32 = g.ws.out.as<float>(); eh.ld_out = V;
-        R.gemm_fused(m.codec_head, hid_t, H, B, V, H, eh);
-        sample(g.ws.out.as<float>(), V, 0, true);
-        const Tok* ct = g.toks_cp.as<Tok>();
-        for (int j = 0; j < G - 1; ++j) {
-            const int M = j == 0 ? 2 * B : B;
-            int nt;
-            if (m.proj) {
-                const void* X;
-                if (j == 0) {
-                    launch_gather_codes(st, m.codec_emb, dt, g.codes.as<unsigned>(), row_stride, d_step, G, 0, (char*)g.cp_in_t.p + (size_t)B * H * es, dt, B, H);
-                    X = g.cp_in_t.p;
-                } else {
-                    launch_gather_codes(st, m.cp_emb[(size_t)j - 1], dt, g.codes.as<unsigned>(), row_stride, d_step, G, j, g.ws.act.p, dt, B, H);
-                    X = g.ws.act.p;
-                }
-                GemmEpi ep{};
-                ep.mode = GEMM_EPI_RESID; ep.bias = m.proj_b; ep.x_out = g.ws.x.as<float>(); ep.xb_out = g.ws.xb.p; ep.nw = m.cp.layers[0].ln1;
-                ep.ss_out = ssA;
-                R.gemm_fused(m.proj, X, H, M, Hc, H, ep);
-                nt = gemm_fused_ntiles(M, Hc, GEMM_EPI_RESID);
-            } else {
-                const float* src;
-                if (j == 0) {
-                    launch_gather_codes(st, m.codec_emb, dt, g.codes.as<unsigned>(), row_stride, d_step, G, 0, g.cp_in_f.as<float>() + (size_t)B * H, F32, B, H);
-                    src = g.cp_in_f.as<float>();
-                } else {
-                    launch_gather_codes(st, m.cp_emb[(size_t)j - 1], dt, g.codes.as<unsigned>(), row_stride, d_step, G, j, g.ws.q.p, F32, B, H);
-                    src = g.ws.q.as<float>();
-                }
-                launch_rows_prep(st, dt, src, m.cp.layers[0].ln1, g.ws.x.as<float>(), g.ws.xb.p, ssA, M, Hc);
-                nt = 1;
-            }
-            nt = R.stack_fused(m.cp, M, j == 0 ? ct : ct + 2 * B + (size_t)j * B, g.cp.kv, nt, true, j != 0);
-            // lm_head j on the newest position of every row (code_predictor.rs:464,514)
-            const size_t roff = j == 0 ? (size_t)B : 0;
-            GemmEpi el{};
-            el.mode = GEMM_EPI_PLAIN; el.ss_in = ssA + roff; el.ntiles_in = nt; el.H_in = Hc; el.eps = c.cp.eps; el.out_f32 = g.ws.out.as<float>();
-            el.ld_out = Vc;
-            R.gemm_fused(m.cp_head[(size_t)j], (char*)g.ws.xb.p + roff * Hc * es, Hc, B, Vc, Hc, el);
-            sample(g.ws.out.as<float>(), Vc, j + 1, false);
-        }
-        EmbedSumArgs ea{};
-        ea.codec_emb = m.codec_emb; ea.cp_emb = (const void* const*)m.cp_emb_ptrs.p; ea.edtype = dt;
-        ea.codes_base = g.codes.as<unsigned>(); ea.row_stride = row_stride; ea.step = d_step;
-        ea.trailing = g.trailing.as<float>(); ea.trailing_len = g.trailing_len.as<int>(); ea.Tt_max = Tt_max;
-        ea.tts_pad = tts_pad_row; ea.G = G; ea.H = H; ea.B = B;
-        launch_embed_sum_norm(st, dt, ea, m.talker.layers[0].ln1, c.talker.eps, g.ws.x.as<float>(), g.ws.xb.p, ssA);
-        launch_advance_step(st, d_step);
-    };
-    auto talker_step_fused = [&]() {
-        launch_make_decode_toks(st, g.row_len.as<int>(), g.toks_dec.as<Tok>(), B, c.talker.window);
-        const int nt = R.stack_fused(m.talker, B, g.toks_dec.as<Tok>(), g.talker.kv, 1, true, true);
-        // post-final-norm hidden state (talker.rs:147-148): input of the codec head and of the code predictor
-        launch_norm_rows(st, dt, g.ws.x.as<float>(), g.ws.ssA.as<float>(), nt, g.ws.ss_ld, m.talker.final_norm, c.talker.eps, hid_t, hid_f, B, H);
-    };
     auto frame_tail = [&](bool eager_trace) {
-        if (fused) { frame_tail_fused(); return; }
-        R.gemm(m.codec_head, hid_t, B, V, H, 1, H);
-        if (eager_trace && trace_l) {
-            // step index is only known on the device; trace copies use the host's mirror of it
-        }
+        (void)eager_trace;
+        R.gemm(m.codec_head, hid_t, B, V, H, 1, H, lo_cp);
         // every sampler also copies the embedding row of the code it drew to where the next pass reads its input
         // (model dtype in front of the H -> Hc projection, f32 when the code predictor is as wide as the talker)
         void* in0 = m.proj ? (void*)((char*)g.cp_in_t.p + (size_t)B * H * es) : (void*)(g.cp_in_f.as<float>() + (size_t)B * H);
@@ -501,28 +431,28 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         const Tok* ct = g.toks_cp.as<Tok>();
         if (m.proj) {
             const int ks = R.ks_for(2 * B, Hc, H);
-            R.gemm(m.proj, g.cp_in_t.p, 2 * B, Hc, H, ks, H);
+            R.gemm(m.proj, g.cp_in_t.p, 2 * B, Hc, H, ks, H, lo_cp);
             launch_resid_norm(st, dt, nullptr, g.ws.part.as<float>(), ks, R.kstride(2 * B, Hc), m.proj_b, nullptr, m.cp.layers[0].ln1, c.cp.eps,
-                              g.ws.x.as<float>(), g.ws.xn.p, nullptr, 2 * B, Hc);
+                              g.ws.x.as<float>(), g.ws.xn.p, nullptr, 2 * B, Hc, g.ws.lo_xn);
         } else {
             launch_resid_norm(st, dt, nullptr, g.cp_in_f.as<float>(), 1, 0, nullptr, nullptr, m.cp.layers[0].ln1, c.cp.eps, g.ws.x.as<float>(),
-                              g.ws.xn.p, nullptr, 2 * B, Hc);
+                              g.ws.xn.p, nullptr, 2 * B, Hc, g.ws.lo_xn);
         }
-        R.stack(m.cp, 2 * B, ct, g.cp.kv, g.ws.xn.p, nullptr);
-        R.gemm(m.cp_head[0], (char*)g.ws.xn.p + (size_t)B * Hc * es, B, Vc, Hc, 1, Hc);
+        R.stack(m.cp, 2 * B, ct, g.cp.kv, g.ws.xn.p, nullptr, true, false, g.ws.lo_xn);
+        R.gemm(m.cp_head[0], (char*)g.ws.xn.p + (size_t)B * Hc * es, B, Vc, Hc, 1, Hc, g.ws.lo_xn);
         sample(g.ws.part.as<float>(), Vc, 1, false, G > 2 ? m.cp_emb[0] : nullptr, inj, in_dt);
         for (int j = 1; j < G - 1; ++j) {  // code_predictor.rs:480-527
             if (m.proj) {
                 const int ks = R.ks_for(B, Hc, H);
-                R.gemm(m.proj, g.ws.act.p, B, Hc, H, ks, H);
+                R.gemm(m.proj, g.ws.act.p, B, Hc, H, ks, H);   // embedding rows: exact in the model dtype, no remainder plane
                 launch_resid_norm(st, dt, nullptr, g.ws.part.as<float>(), ks, R.kstride(B, Hc), m.proj_b, nullptr, m.cp.layers[0].ln1, c.cp.eps,
-                                  g.ws.x.as<float>(), g.ws.xn.p, nullptr, B, Hc);
+                                  g.ws.x.as<float>(), g.ws.xn.p, nullptr, B, Hc, g.ws.lo_xn);
             } else {
                 launch_resid_norm(st, dt, nullptr, g.ws.q.as<float>(), 1, 0, nullptr, nullptr, m.cp.layers[0].ln1, c.cp.eps, g.ws.x.as<float>(), g.ws.xn.p,
-                                  nullptr, B, Hc);
+                                  nullptr, B, Hc, g.ws.lo_xn);
             }
-            R.stack(m.cp, B, ct + 2 * B + (size_t)j * B, g.cp.kv, g.ws.xn.p, nullptr, true, true);
-            R.gemm(m.cp_head[(size_t)j], g.ws.xn.p, B, Vc, Hc, 1, Hc);
+            R.stack(m.cp, B, ct + 2 * B + (size_t)j * B, g.cp.kv, g.ws.xn.p, nullptr, true, true, g.ws.lo_xn);
+            R.gemm(m.cp_head[(size_t)j], g.ws.xn.p, B, Vc, Hc, 1, Hc, g.ws.lo_xn);
             sample(g.ws.part.as<float>(), Vc, j + 1, false, j + 1 < G - 1 ? m.cp_emb[(size_t)j] : nullptr, inj, in_dt);
         }
         // ---- next talker input (talker.rs:461-479 + generation.rs:1096-1106) and its layer-0 norm
@@ -531,13 +461,12 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         ea.codes_base = g.codes.as<unsigned>(); ea.row_stride = row_stride; ea.step = d_step;
         ea.trailing = g.trailing.as<float>(); ea.trailing_len = g.trailing_len.as<int>(); ea.Tt_max = Tt_max;
         ea.tts_pad = tts_pad_row; ea.G = G; ea.H = H; ea.B = B;
-        launch_embed_sum_norm(st, dt, ea, m.talker.layers[0].ln1, c.talker.eps, g.ws.x.as<float>(), g.ws.xn.p);
+        launch_embed_sum_norm(st, dt, ea, m.talker.layers[0].ln1, c.talker.eps, g.ws.x.as<float>(), g.ws.xn.p, g.ws.lo_xn);
         launch_advance_step(st, d_step);
     };
     auto talker_step = [&]() {  // generation.rs:1002-1026
-        if (fused) { talker_step_fused(); return; }
         launch_make_decode_toks(st, g.row_len.as<int>(), g.toks_dec.as<Tok>(), B, c.talker.window);
-        R.stack(m.talker, B, g.toks_dec.as<Tok>(), g.talker.kv, hid_t, hid_f, true, true);
+        R.stack(m.talker, B, g.toks_dec.as<Tok>(), g.talker.kv, hid_t, hid_f, true, true, lo_cp);
     };
     auto trace_copy = [&](int step) {
         // logits of this frame are recomputed into the partial buffer by frame_tail; hidden is in hid_f
@@ -545,7 +474,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
             QTTS_HIP(hipMemcpy2DAsync(g.trace_hidden.as<float>() + (size_t)step * H, (size_t)max_new * H * 4, hid_f, (size_t)H * 4,
                                       (size_t)H * 4, B, hipMemcpyDeviceToDevice, st));
         if (trace_l) {
-            R.gemm(m.codec_head, hid_t, B, V, H, 1, H);
+            R.gemm(m.codec_head, hid_t, B, V, H, 1, H, lo_cp);
             QTTS_HIP(hipMemcpy2DAsync(g.trace_logits.as<float>() + (size_t)step * V, (size_t)max_new * V * 4, g.ws.part.p, (size_t)V * 4,
                                       (size_t)V * 4, B, hipMemcpyDeviceToDevice, st));
         }

@@ -75,7 +75,7 @@ void launch_qkv_post(hipStream_t st, int dtype, const QkvPostArgs& a, const KVVi
 // ------------------------------------------------------------------------------------------------
 template <typename T, int D, int REP>
 __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ q, const Tok* __restrict__ toks, KVView kv,
-                                                        int layer, int nh, float scale, T* out) {
+                                                        int layer, int nh, float scale, T* out, long out_lo) {
     constexpr int LPK = D / 8;     // lanes per key (8 head dims each)
     constexpr int KPW = 64 / LPK;  // keys per wave per iteration
     __shared__ float sm[4][REP][LPK][10];
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) ot[e] = ot[e] / lt;
-        store8(out + ((long)m * nh + (long)g * REP + h) * D + j * 8, ot);
+        store8_split<T>(out + ((long)m * nh + (long)g * REP + h) * D + j * 8, out_lo, ot);
     }
 }
 
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
 // token's newest key is its own position and no other token of the launch attends to it (decode steps, the code
 // predictor's single-token passes); prefill chunks use the two-kernel path.
 template <typename T, int D, int REP>
-__global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KVView kv, float scale, T* out) {
+__global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KVView kv, float scale, T* out, long out_lo) {
     constexpr int LPK = D / 8, KPW = 64 / LPK, HALF = D / 2;
     __shared__ float sm[4][REP][LPK][10];
     __shared__ float qs[REP][D];
@@ -316,59 +316,61 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KV
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) ot[e] = ot[e] / lt;
-        store8(out + ((long)m * a.nh + (long)g * REP + h) * D + j * 8, ot);
+        store8_split<T>(out + ((long)m * a.nh + (long)g * REP + h) * D + j * 8, out_lo, ot);
     }
 }
 
 template <typename T, int D>
-static void launch_attn_decode_rep(hipStream_t st, const QkvPostArgs& a, const KVView& kv, float scale, T* out) {
+static void launch_attn_decode_rep(hipStream_t st, const QkvPostArgs& a, const KVView& kv, float scale, T* out, long out_lo) {
     const int rep = a.nh / kv.nkv;
     dim3 grid(a.M, kv.nkv), block(256);
     switch (rep) {
-        case 1: hipLaunchKernelGGL((attention_decode_kernel<T, D, 1>), grid, block, 0, st, a, kv, scale, out); break;
-        case 2: hipLaunchKernelGGL((attention_decode_kernel<T, D, 2>), grid, block, 0, st, a, kv, scale, out); break;
-        case 4: hipLaunchKernelGGL((attention_decode_kernel<T, D, 4>), grid, block, 0, st, a, kv, scale, out); break;
-        case 8: hipLaunchKernelGGL((attention_decode_kernel<T, D, 8>), grid, block, 0, st, a, kv, scale, out); break;
+        case 1: hipLaunchKernelGGL((attention_decode_kernel<T, D, 1>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
+        case 2: hipLaunchKernelGGL((attention_decode_kernel<T, D, 2>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
+        case 4: hipLaunchKernelGGL((attention_decode_kernel<T, D, 4>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
+        case 8: hipLaunchKernelGGL((attention_decode_kernel<T, D, 8>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
         default: throw Error(ERR_SHAPE, "attention: heads per kv head must be 1, 2, 4 or 8");
     }
 }
 
-void launch_attention_decode(hipStream_t st, int dtype, const QkvPostArgs& a, const KVView& kv, float scale, void* out) {
+void launch_attention_decode(hipStream_t st, int dtype, const QkvPostArgs& a, const KVView& kv, float scale, void* out, long out_lo) {
     QTTS_CHECK(a.d == 64 || a.d == 128, ERR_SHAPE, "attention: head_dim must be 64 or 128");
     QTTS_CHECK(a.M >= 1 && a.nh >= 1 && a.nkv >= 1 && a.nh % a.nkv == 0 && kv.d == a.d && kv.nkv == a.nkv, ERR_SHAPE, "attention: bad shape");
     if (dtype == BF16) {
-        if (a.d == 128) launch_attn_decode_rep<bf16_t, 128>(st, a, kv, scale, (bf16_t*)out);
-        else launch_attn_decode_rep<bf16_t, 64>(st, a, kv, scale, (bf16_t*)out);
+        if (a.d == 128) launch_attn_decode_rep<bf16_t, 128>(st, a, kv, scale, (bf16_t*)out, out_lo);
+        else launch_attn_decode_rep<bf16_t, 64>(st, a, kv, scale, (bf16_t*)out, out_lo);
     } else {
-        if (a.d == 128) launch_attn_decode_rep<float, 128>(st, a, kv, scale, (float*)out);
-        else launch_attn_decode_rep<float, 64>(st, a, kv, scale, (float*)out);
+        QTTS_CHECK(out_lo == 0, ERR_BAD_ARG, "attention: a remainder plane exists for bf16 activations only");
+        if (a.d == 128) launch_attn_decode_rep<float, 128>(st, a, kv, scale, (float*)out, 0);
+        else launch_attn_decode_rep<float, 64>(st, a, kv, scale, (float*)out, 0);
     }
 }
 
 template <typename T, int D>
 static void launch_attn_rep(hipStream_t st, const float* q, const Tok* toks, const KVView& kv, int layer, int M, int nh,
-                            float scale, T* out) {
+                            float scale, T* out, long out_lo) {
     const int rep = nh / kv.nkv;
     dim3 grid(M, kv.nkv), block(256);
     switch (rep) {
-        case 1: hipLaunchKernelGGL((attention_kernel<T, D, 1>), grid, block, 0, st, q, toks, kv, layer, nh, scale, out); break;
-        case 2: hipLaunchKernelGGL((attention_kernel<T, D, 2>), grid, block, 0, st, q, toks, kv, layer, nh, scale, out); break;
-        case 4: hipLaunchKernelGGL((attention_kernel<T, D, 4>), grid, block, 0, st, q, toks, kv, layer, nh, scale, out); break;
-        case 8: hipLaunchKernelGGL((attention_kernel<T, D, 8>), grid, block, 0, st, q, toks, kv, layer, nh, scale, out); break;
+        case 1: hipLaunchKernelGGL((attention_kernel<T, D, 1>), grid, block, 0, st, q, toks, kv, layer, nh, scale, out, out_lo); break;
+        case 2: hipLaunchKernelGGL((attention_kernel<T, D, 2>), grid, block, 0, st, q, toks, kv, layer, nh, scale, out, out_lo); break;
+        case 4: hipLaunchKernelGGL((attention_kernel<T, D, 4>), grid, block, 0, st, q, toks, kv, layer, nh, scale, out, out_lo); break;
+        case 8: hipLaunchKernelGGL((attention_kernel<T, D, 8>), grid, block, 0, st, q, toks, kv, layer, nh, scale, out, out_lo); break;
         default: throw Error(ERR_SHAPE, "attention: heads per kv head must be 1, 2, 4 or 8");
     }
 }
 
 void launch_attention(hipStream_t st, int dtype, const float* q, const Tok* toks, const KVView& kv, int layer, int M, int nh,
-                      float scale, void* out) {
+                      float scale, void* out, long out_lo) {
     QTTS_CHECK(kv.d == 64 || kv.d == 128, ERR_SHAPE, "attention: head_dim must be 64 or 128");
     QTTS_CHECK(M >= 1 && nh % kv.nkv == 0, ERR_SHAPE, "attention: bad head counts");
     if (dtype == BF16) {
-        if (kv.d == 128) launch_attn_rep<bf16_t, 128>(st, q, toks, kv, layer, M, nh, scale, (bf16_t*)out);
-        else launch_attn_rep<bf16_t, 64>(st, q, toks, kv, layer, M, nh, scale, (bf16_t*)out);
+        if (kv.d == 128) launch_attn_rep<bf16_t, 128>(st, q, toks, kv, layer, M, nh, scale, (bf16_t*)out, out_lo);
+        else launch_attn_rep<bf16_t, 64>(st, q, toks, kv, layer, M, nh, scale, (bf16_t*)out, out_lo);
     } else {
-        if (kv.d == 128) launch_attn_rep<float, 128>(st, q, toks, kv, layer, M, nh, scale, (float*)out);
-        else launch_attn_rep<float, 64>(st, q, toks, kv, layer, M, nh, scale, (float*)out);
+        QTTS_CHECK(out_lo == 0, ERR_BAD_ARG, "attention: a remainder plane exists for bf16 activations only");
+        if (kv.d == 128) launch_attn_rep<float, 128>(st, q, toks, kv, layer, M, nh, scale, (float*)out, 0);
+        else launch_attn_rep<float, 64>(st, q, toks, kv, layer, M, nh, scale, (float*)out, 0);
     }
 }
 

@@ -12,7 +12,7 @@ namespace qtts {
 // m = sqrt(mean(x^2) + eps)   (qwen_tts/src/nn/norm.rs:17-23 -> candle_nn::rms_norm: (x / m) * w).
 template <typename T>
 __device__ __forceinline__ void rmsnorm_tail(const float* xrow, float ss_local, const float* __restrict__ w, float eps,
-                                             T* xn_row, float* xn_f32_row, int H, float* red) {
+                                             T* xn_row, float* xn_f32_row, int H, float* red, long xn_lo) {
     const float ss = block_sum(ss_local, red);
     const float m = sqrtf(ss / (float)H + eps);
     for (int i = threadIdx.x * 4; i < H; i += blockDim.x * 4) {
@@ -20,10 +20,10 @@ __device__ __forceinline__ void rmsnorm_tail(const float* xrow, float ss_local, 
         const float4 g = *reinterpret_cast<const float4*>(w + i);
         float4 y = make_float4(x.x / m * g.x, x.y / m * g.y, x.z / m * g.z, x.w / m * g.w);
         if (xn_f32_row) *reinterpret_cast<float4*>(xn_f32_row + i) = y;
-        xn_row[i] = from_f32<T>(y.x);
-        xn_row[i + 1] = from_f32<T>(y.y);
-        xn_row[i + 2] = from_f32<T>(y.z);
-        xn_row[i + 3] = from_f32<T>(y.w);
+        store_split<T>(xn_row + i, xn_lo, y.x);
+        store_split<T>(xn_row + i + 1, xn_lo, y.y);
+        store_split<T>(xn_row + i + 2, xn_lo, y.z);
+        store_split<T>(xn_row + i + 3, xn_lo, y.w);
     }
 }
 
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(const float* __restrict
                                                          int KS, long ks_stride, const float* __restrict__ bias,
                                                          const float* __restrict__ scale,
                                                          const float* __restrict__ norm_w, float eps, float* resid_out,
-                                                         T* xn, float* xn_f32, int H) {
+                                                         T* xn, float* xn_f32, int H, long xn_lo) {
     __shared__ float red[32];
     constexpr int RMAX = 4;  // rows up to 4096 wide stay in registers between the two passes
     const long row = blockIdx.x;
@@ -91,10 +91,10 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(const float* __restrict
                 const float4 y = make_float4(x.x / m * g.x, x.y / m * g.y, x.z / m * g.z, x.w / m * g.w);
                 if (xn_f32) *reinterpret_cast<float4*>(xn_f32 + row * H + i) = y;
                 T* o = xn + row * H + i;
-                o[0] = from_f32<T>(y.x);
-                o[1] = from_f32<T>(y.y);
-                o[2] = from_f32<T>(y.z);
-                o[3] = from_f32<T>(y.w);
+                store_split<T>(o, xn_lo, y.x);
+                store_split<T>(o + 1, xn_lo, y.y);
+                store_split<T>(o + 2, xn_lo, y.z);
+                store_split<T>(o + 3, xn_lo, y.w);
             }
         }
         return;
@@ -104,26 +104,27 @@ __global__ __launch_bounds__(256) void resid_norm_kernel(const float* __restrict
         *reinterpret_cast<float4*>(resid_out + row * H + i) = s;
         ss += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
     }
-    if (norm_w) rmsnorm_tail<T>(resid_out + row * H, ss, norm_w, eps, xn + row * H, xn_f32 ? xn_f32 + row * H : nullptr, H, red);
+    if (norm_w) rmsnorm_tail<T>(resid_out + row * H, ss, norm_w, eps, xn + row * H, xn_f32 ? xn_f32 + row * H : nullptr, H, red, xn_lo);
 }
 
 void launch_resid_norm(hipStream_t st, int dtype, const float* resid, const float* part, int KS, long ks_stride,
                        const float* bias, const float* scale, const float* norm_w, float eps, float* resid_out, void* xn,
-                       float* xn_f32, int M, int H) {
+                       float* xn_f32, int M, int H, long xn_lo) {
     QTTS_CHECK(H % 4 == 0 && M >= 1, ERR_SHAPE, "resid_norm: H must be a multiple of 4");
     QTTS_CHECK(resid_out != nullptr && (norm_w == nullptr || xn != nullptr), ERR_BAD_ARG, "resid_norm: null output");
+    QTTS_CHECK(xn_lo == 0 || dtype == BF16, ERR_BAD_ARG, "resid_norm: a remainder plane exists for bf16 activations only");
     if (dtype == BF16)
         hipLaunchKernelGGL(resid_norm_kernel<bf16_t>, dim3(M), dim3(256), 0, st, resid, part, KS, ks_stride, bias, scale, norm_w, eps,
-                           resid_out, (bf16_t*)xn, xn_f32, H);
+                           resid_out, (bf16_t*)xn, xn_f32, H, xn_lo);
     else
         hipLaunchKernelGGL(resid_norm_kernel<float>, dim3(M), dim3(256), 0, st, resid, part, KS, ks_stride, bias, scale, norm_w, eps,
-                           resid_out, (float*)xn, xn_f32, H);
+                           resid_out, (float*)xn, xn_f32, H, 0L);
 }
 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void swiglu_kernel(const float* __restrict__ part, int KS, long ks_stride, T* act, int I,
-                                                     long total4) {
+                                                     long total4, long act_lo) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (long)gridDim.x * blockDim.x) {
         const long row = (e * 4) / I;
         const int i = (int)((e * 4) % I);
@@ -131,41 +132,43 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const float* __restrict__ p
         const float4 g = slab_sum4(pg, KS, ks_stride);
         const float4 u = slab_sum4(pg + I, KS, ks_stride);
         T* o = act + row * I + i;
-        o[0] = from_f32<T>(g.x / (1.0f + expf(-g.x)) * u.x);
-        o[1] = from_f32<T>(g.y / (1.0f + expf(-g.y)) * u.y);
-        o[2] = from_f32<T>(g.z / (1.0f + expf(-g.z)) * u.z);
-        o[3] = from_f32<T>(g.w / (1.0f + expf(-g.w)) * u.w);
+        store_split<T>(o, act_lo, g.x / (1.0f + expf(-g.x)) * u.x);
+        store_split<T>(o + 1, act_lo, g.y / (1.0f + expf(-g.y)) * u.y);
+        store_split<T>(o + 2, act_lo, g.z / (1.0f + expf(-g.z)) * u.z);
+        store_split<T>(o + 3, act_lo, g.w / (1.0f + expf(-g.w)) * u.w);
     }
 }
 
-void launch_swiglu(hipStream_t st, int dtype, const float* part, int KS, long ks_stride, void* act, int M, int I) {
+void launch_swiglu(hipStream_t st, int dtype, const float* part, int KS, long ks_stride, void* act, int M, int I, long act_lo) {
     QTTS_CHECK(I % 4 == 0 && M >= 1, ERR_SHAPE, "swiglu: I must be a multiple of 4");
+    QTTS_CHECK(act_lo == 0 || dtype == BF16, ERR_BAD_ARG, "swiglu: a remainder plane exists for bf16 activations only");
     const long total4 = (long)M * I / 4;
     const int blocks = (int)std::min<long>((total4 + 255) / 256, 2048);
-    if (dtype == BF16) hipLaunchKernelGGL(swiglu_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, part, KS, ks_stride, (bf16_t*)act, I, total4);
-    else hipLaunchKernelGGL(swiglu_kernel<float>, dim3(blocks), dim3(256), 0, st, part, KS, ks_stride, (float*)act, I, total4);
+    if (dtype == BF16) hipLaunchKernelGGL(swiglu_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, part, KS, ks_stride, (bf16_t*)act, I, total4, act_lo);
+    else hipLaunchKernelGGL(swiglu_kernel<float>, dim3(blocks), dim3(256), 0, st, part, KS, ks_stride, (float*)act, I, total4, 0L);
 }
 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void bias_act_kernel(const float* __restrict__ part, int KS, long ks_stride,
-                                                       const float* __restrict__ bias, int act, T* out, int N, long total) {
+                                                       const float* __restrict__ bias, int act, T* out, int N, long total, long out_lo) {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         float s = part[e];
         for (int k = 1; k < KS; ++k) s += part[k * ks_stride + e];
         if (bias) s += bias[e % N];
         if (act == 1) s = s / (1.0f + expf(-s));
         else if (act == 2) s = 0.5f * s * (1.0f + erff(s * 0.70710678118654752440f));  // exact GELU (Tensor::gelu_erf)
-        out[e] = from_f32<T>(s);
+        store_split<T>(out + e, out_lo, s);
     }
 }
 
 void launch_bias_act(hipStream_t st, const float* part, int KS, long ks_stride, const float* bias, int act, void* out,
-                     int out_dtype, int M, int N) {
+                     int out_dtype, int M, int N, long out_lo) {
     const long total = (long)M * N;
     const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
-    if (out_dtype == BF16) hipLaunchKernelGGL(bias_act_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, part, KS, ks_stride, bias, act, (bf16_t*)out, N, total);
-    else hipLaunchKernelGGL(bias_act_kernel<float>, dim3(blocks), dim3(256), 0, st, part, KS, ks_stride, bias, act, (float*)out, N, total);
+    QTTS_CHECK(out_lo == 0 || out_dtype == BF16, ERR_BAD_ARG, "bias_act: a remainder plane exists for bf16 activations only");
+    if (out_dtype == BF16) hipLaunchKernelGGL(bias_act_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, part, KS, ks_stride, bias, act, (bf16_t*)out, N, total, out_lo);
+    else hipLaunchKernelGGL(bias_act_kernel<float>, dim3(blocks), dim3(256), 0, st, part, KS, ks_stride, bias, act, (float*)out, N, total, 0L);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -217,7 +220,7 @@ void launch_assemble(hipStream_t st, const float* text_rows, const int* text_idx
 // (nn/generation.rs:1096-1106) + the next layer-0 input norm.  Adds run in codebook order in f32.
 template <typename TE, typename T>
 __global__ __launch_bounds__(256) void embed_sum_norm_kernel(EmbedSumArgs a, const float* __restrict__ norm_w, float eps,
-                                                             float* resid_out, T* xn, float* ss_out) {
+                                                             float* resid_out, T* xn, long xn_lo) {
     __shared__ float red[32];
     __shared__ const TE* rowp[64];  // embedding row of every codebook, staged so that the gathers below are independent loads
     const int b = blockIdx.x;
@@ -253,79 +256,22 @@ __global__ __launch_bounds__(256) void embed_sum_norm_kernel(EmbedSumArgs a, con
         }
         float t8[8];
         load8(add + i, t8);
-        float nw[8];
-        if (ss_out) load8(norm_w + i, nw);
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             v[q] = v[q] + t8[q];
             ss += v[q] * v[q];
         }
         store8(resid_out + (long)b * a.H + i, v);
-        if (ss_out) {  // split norm: 1/rms is applied by the consuming GEMM
-            float y[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) y[q] = v[q] * nw[q];
-            store8(xn + (long)b * a.H + i, y);
-        }
     }
-    if (ss_out) {
-        const float tot = block_sum(ss, red);
-        if (threadIdx.x == 0) ss_out[b] = tot;
-        return;
-    }
-    rmsnorm_tail<T>(resid_out + (long)b * a.H, ss, norm_w, eps, xn + (long)b * a.H, nullptr, a.H, red);
+    rmsnorm_tail<T>(resid_out + (long)b * a.H, ss, norm_w, eps, xn + (long)b * a.H, nullptr, a.H, red, xn_lo);
 }
 
 void launch_embed_sum_norm(hipStream_t st, int dtype, const EmbedSumArgs& a, const float* norm_w, float eps, float* resid_out,
-                           void* xn, float* ss_out) {
+                           void* xn, long xn_lo) {
     QTTS_CHECK(a.B >= 1 && a.H % 8 == 0 && a.G >= 1 && a.G <= 64, ERR_SHAPE, "embed_sum: bad shape");
-    if (a.edtype == BF16 && dtype == BF16) hipLaunchKernelGGL((embed_sum_norm_kernel<bf16_t, bf16_t>), dim3(a.B), dim3(256), 0, st, a, norm_w, eps, resid_out, (bf16_t*)xn, ss_out);
-    else if (a.edtype == F32 && dtype == F32) hipLaunchKernelGGL((embed_sum_norm_kernel<float, float>), dim3(a.B), dim3(256), 0, st, a, norm_w, eps, resid_out, (float*)xn, ss_out);
+    if (a.edtype == BF16 && dtype == BF16) hipLaunchKernelGGL((embed_sum_norm_kernel<bf16_t, bf16_t>), dim3(a.B), dim3(256), 0, st, a, norm_w, eps, resid_out, (bf16_t*)xn, xn_lo);
+    else if (a.edtype == F32 && dtype == F32) hipLaunchKernelGGL((embed_sum_norm_kernel<float, float>), dim3(a.B), dim3(256), 0, st, a, norm_w, eps, resid_out, (float*)xn, 0L);
     else throw Error(ERR_BAD_ARG, "embed_sum: embedding and activation dtypes must match");
-}
-
-// Split RMSNorm helpers for the fused decode GEMMs (nn/norm.rs:17-23): a row producer emits xb = T(x * w) and the
-// row's sum of squares; the consuming GEMM divides by sqrt(ss / H + eps).
-//   rows_prep: x (f32 rows) -> [x_out copy], xb, ss[row]            norm_rows: x, ss partials -> T(x / m * w) [+ f32 copy]
-template <typename T>
-__global__ __launch_bounds__(256) void rows_prep_kernel(const float* __restrict__ x, const float* __restrict__ nw, float* x_out, T* xb,
-                                                        float* ss_out, int H) {
-    __shared__ float red[32];
-    const long row = blockIdx.x;
-    float ss = 0.f;
-    for (int i = threadIdx.x; i < H; i += blockDim.x) {
-        const float v = x[row * H + i];
-        if (x_out) x_out[row * H + i] = v;
-        xb[row * H + i] = from_f32<T>(v * nw[i]);
-        ss += v * v;
-    }
-    const float tot = block_sum(ss, red);
-    if (threadIdx.x == 0) ss_out[row] = tot;
-}
-void launch_rows_prep(hipStream_t st, int dtype, const float* x, const float* nw, float* x_out, void* xb, float* ss_out, int M, int H) {
-    QTTS_CHECK(M >= 1 && H >= 1 && x && nw && xb && ss_out, ERR_BAD_ARG, "rows_prep: bad argument");
-    if (dtype == BF16) hipLaunchKernelGGL(rows_prep_kernel<bf16_t>, dim3(M), dim3(256), 0, st, x, nw, x_out, (bf16_t*)xb, ss_out, H);
-    else hipLaunchKernelGGL(rows_prep_kernel<float>, dim3(M), dim3(256), 0, st, x, nw, x_out, (float*)xb, ss_out, H);
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void norm_rows_kernel(const float* __restrict__ x, const float* __restrict__ ss, int ntiles, long ss_ld,
-                                                        const float* __restrict__ nw, float eps, T* out, float* out_f32, int H) {
-    const long row = blockIdx.x;
-    float tot = 0.f;
-    for (int t = 0; t < ntiles; ++t) tot += ss[t * ss_ld + row];
-    const float m = sqrtf(tot / (float)H + eps);
-    for (int i = threadIdx.x; i < H; i += blockDim.x) {
-        const float y = x[row * H + i] / m * nw[i];
-        out[row * H + i] = from_f32<T>(y);
-        if (out_f32) out_f32[row * H + i] = y;
-    }
-}
-void launch_norm_rows(hipStream_t st, int dtype, const float* x, const float* ss, int ntiles, long ss_ld, const float* nw, float eps,
-                      void* out, float* out_f32, int M, int H) {
-    QTTS_CHECK(M >= 1 && H >= 1 && ntiles >= 1 && x && ss && nw && out, ERR_BAD_ARG, "norm_rows: bad argument");
-    if (dtype == BF16) hipLaunchKernelGGL(norm_rows_kernel<bf16_t>, dim3(M), dim3(256), 0, st, x, ss, ntiles, ss_ld, nw, eps, (bf16_t*)out, out_f32, H);
-    else hipLaunchKernelGGL(norm_rows_kernel<float>, dim3(M), dim3(256), 0, st, x, ss, ntiles, ss_ld, nw, eps, (float*)out, out_f32, H);
 }
 
 // sum_ref_code_embeddings (qwen_tts/src/nn/generation.rs:242-273): dst[rows[i]] = codec_emb[c0] + sum_g cp_emb[g-1][c_g]

@@ -14,7 +14,26 @@
 #include <cstdlib>
 #include <algorithm>
 
+#ifndef QTTS_NT_WEIGHTS
+#define QTTS_NT_WEIGHTS 1
+#endif
+
 namespace qtts {
+
+// Tuning switches, read from the environment once per process (the first call from any thread fixes them for all).
+struct GemmEnv {
+    int force_kind, force_nt, force_nch, min_blocks;
+    bool xcd_order, conv_halo_off;
+};
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+static const GemmEnv& gemm_env() {
+    static const GemmEnv e{env_int("QTTS_GEMM_KIND", -1), env_int("QTTS_GEMM_NT", 0), env_int("QTTS_GEMM_NCH", 0),
+                           env_int("QTTS_GEMM_MIN_BLOCKS", 192), env_int("QTTS_GEMM_XCD", 1) != 0, env_int("QTTS_CONV_HALO", 1) == 0};
+    return e;
+}
 
 template <typename T>
 struct Frag;
@@ -26,6 +45,15 @@ struct Frag<bf16_t> {
     __device__ __forceinline__ void load(const bf16_t* p) {
         v[0] = *reinterpret_cast<const bf16x8_t*>(p);
         v[1] = *reinterpret_cast<const bf16x8_t*>(p + 8);
+    }
+    // weights that one block reads once: non-temporal, so that they do not displace the activations in L2
+    __device__ __forceinline__ void load_stream(const bf16_t* p) {
+        if (QTTS_NT_WEIGHTS) {
+            v[0] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(p));
+            v[1] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(p + 8));
+        } else {
+            load(p);
+        }
     }
     static __device__ __forceinline__ f32x4_t mma(const Frag& a, const Frag& b, f32x4_t c) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v[0], b.v[0], c, 0, 0, 0);
@@ -43,6 +71,15 @@ struct Frag<float> {
         const float4 b = *reinterpret_cast<const float4*>(p + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     }
+    __device__ __forceinline__ void load_stream(const float* p) {
+        if (QTTS_NT_WEIGHTS) {
+            const f32x4_t a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+            const f32x4_t b = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p + 4));
+            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        } else {
+            load(p);
+        }
+    }
     static __device__ __forceinline__ f32x4_t mma(const Frag& a, const Frag& b, f32x4_t c) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
@@ -50,10 +87,12 @@ struct Frag<float> {
     }
 };
 
-template <typename T, int MT, int NT>
+// LO: X carries a second plane `x_lo` elements behind it (the rounding remainder of the activations, see
+// device_utils.hpp store_split); both planes are multiplied, so the product sees the activations to ~16 bits.
+template <typename T, int MT, int NT, bool LO>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ W, const T* __restrict__ X,
                                                           float* __restrict__ out, int N, int K, int KS, int ldx,
-                                                          long out_ks_stride) {
+                                                          long out_ks_stride, long x_lo) {
     using F = Frag<T>;
     __shared__ f32x4_t red[4][MT * NT][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -79,19 +118,27 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ 
 
 
     // two register stages: the loads of chunk c+1 are in flight while chunk c feeds the MFMAs
-    F a0[NT], b0[MT], a1[NT], b1[MT];
-    auto load_stage = [&](F(&a)[NT], F(&b)[MT], int c) {
+    constexpr int MB = LO ? 2 * MT : MT;  // X fragments per stage: the lo plane's follow the hi plane's
+    F a0[NT], b0[MB], a1[NT], b1[MB];
+    auto load_stage = [&](F(&a)[NT], F(&b)[MB], int c) {
         const size_t off = (size_t)c * F::CHUNK;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) a[j].load(wp[j] + off);
+        for (int j = 0; j < NT; ++j) a[j].load_stream(wp[j] + off);
 #pragma unroll
         for (int i = 0; i < MT; ++i) b[i].load(xp[i] + off);
+        if constexpr (LO) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) b[MT + i].load(xp[i] + x_lo + off);
+        }
     };
-    auto mma_stage = [&](const F(&a)[NT], const F(&b)[MT]) {
+    auto mma_stage = [&](const F(&a)[NT], const F(&b)[MB]) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[j], b[i], acc[i][j]);
+            for (int j = 0; j < NT; ++j) {
+                acc[i][j] = F::mma(a[j], b[i], acc[i][j]);
+                if constexpr (LO) acc[i][j] = F::mma(a[j], b[MT + i], acc[i][j]);
+            }
     };
     if (c0 < c1) load_stage(a0, b0, c0);
     for (int c = c0; c < c1; c += 2) {
@@ -127,13 +174,14 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ 
 // front straight to registers, X fragment blocks are DMA'd into LDS (lane-linear 1 KiB blocks laid
 // out exactly as the MFMA B operand wants them, so the later ds_read_b128 are conflict-free), one
 // barrier, then the MFMAs run out of registers + LDS.  K is split across blocks only (grid.y).
-template <typename T, int MT, int NT, int NCH>
+template <typename T, int MT, int NT, int NCH, bool LO>
 __global__ __launch_bounds__(256) void gemm_ldsx_kernel(const T* __restrict__ W, const T* __restrict__ X,
                                                         float* __restrict__ out, int N, int K, int ldx,
-                                                        long out_ks_stride, int GX, int KS, int Z) {
+                                                        long out_ks_stride, int GX, int KS, int Z, long x_lo) {
     using F = Frag<T>;
     constexpr int HALF = 16 / sizeof(T);  // elements per 16-byte half fragment
-    __shared__ uint4 xs[NCH * MT * 2 * 64];
+    constexpr int NFB = NCH * MT * 2;      // 1 KiB fragment blocks of one plane
+    __shared__ uint4 xs[(LO ? 2 : 1) * NFB * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
@@ -152,11 +200,11 @@ __global__ __launch_bounds__(256) void gemm_ldsx_kernel(const T* __restrict__ W,
     const int row0 = bz * (16 * MT);
     const size_t kbeg = (size_t)ks * NCH * F::CHUNK;
 
-    // X fragment blocks -> LDS (asynchronous, no VGPRs)
-    constexpr int NFB = NCH * MT * 2;
-    for (int fb = wave; fb < NFB; fb += 4) {
-        const int c = fb / (MT * 2), i = (fb >> 1) % MT, h = fb & 1;
-        const T* src = X + (size_t)(row0 + 16 * i + r) * ldx + kbeg + (size_t)c * F::CHUNK + g * F::EPL + h * HALF;
+    // X fragment blocks -> LDS (asynchronous, no VGPRs); the lo plane's blocks follow the hi plane's
+    for (int fb = wave; fb < (LO ? 2 : 1) * NFB; fb += 4) {
+        const int pl = fb / NFB, f = fb % NFB;
+        const int c = f / (MT * 2), i = (f >> 1) % MT, h = f & 1;
+        const T* src = X + (pl ? x_lo : 0) + (size_t)(row0 + 16 * i + r) * ldx + kbeg + (size_t)c * F::CHUNK + g * F::EPL + h * HALF;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(xs + fb * 64), 16, 0, 0);
     }
@@ -166,7 +214,12 @@ __global__ __launch_bounds__(256) void gemm_ldsx_kernel(const T* __restrict__ W,
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-            a[c][j].load(W + (size_t)(n0 + 16 * j + r) * K + kbeg + (size_t)c * F::CHUNK + g * F::EPL);
+        {
+            // one row slice: every weight byte is read by exactly one block (streamed); several: the slices share it through L2
+            const T* wsrc = W + (size_t)(n0 + 16 * j + r) * K + kbeg + (size_t)c * F::CHUNK + g * F::EPL;
+            if (Z > 1) a[c][j].load(wsrc);
+            else a[c][j].load_stream(wsrc);
+        }
 
     f32x4_t acc[MT][NT];
 #pragma unroll
@@ -186,6 +239,14 @@ __global__ __launch_bounds__(256) void gemm_ldsx_kernel(const T* __restrict__ W,
             __builtin_memcpy((char*)&b + 16, &h1, 16);
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[c][j], b, acc[i][j]);
+            if constexpr (LO) {
+                const uint4 l0 = xs[(NFB + (c * MT + i) * 2 + 0) * 64 + lane];
+                const uint4 l1 = xs[(NFB + (c * MT + i) * 2 + 1) * 64 + lane];
+                __builtin_memcpy(&b, &l0, 16);
+                __builtin_memcpy((char*)&b + 16, &l1, 16);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[c][j], b, acc[i][j]);
+            }
         }
     }
     float* o = out + (size_t)ks * out_ks_stride;
@@ -196,52 +257,48 @@ __global__ __launch_bounds__(256) void gemm_ldsx_kernel(const T* __restrict__ W,
             *reinterpret_cast<f32x4_t*>(o + (size_t)(row0 + 16 * i + r) * N + n0 + 16 * j + 4 * g) = acc[i][j];
 }
 
-template <typename T, int MT, int NT, int NCH>
-static void launch_ldsx(hipStream_t st, const T* W, const T* X, float* out, int Mpad, int N, int K, int ldx) {
+template <typename T, int MT, int NT, int NCH, bool LO>
+static void launch_ldsx(hipStream_t st, const T* W, const T* X, float* out, int Mpad, int N, int K, int ldx, long x_lo) {
     const int KS = K / (NCH * Frag<T>::CHUNK);
     const int GX = N / (64 * NT), Z = Mpad / (16 * MT);
-    static const bool xcd_order = !(getenv("QTTS_GEMM_XCD") && atoi(getenv("QTTS_GEMM_XCD")) == 0);
+    const bool xcd_order = gemm_env().xcd_order;
     if (Z > 1 && xcd_order) {
         const int groups = (GX * KS + 7) / 8;
-        hipLaunchKernelGGL((gemm_ldsx_kernel<T, MT, NT, NCH>), dim3(groups * 8 * Z), dim3(256), 0, st, W, X, out, N, K, ldx, (long)Mpad * N,
-                           GX, KS, Z);
+        hipLaunchKernelGGL((gemm_ldsx_kernel<T, MT, NT, NCH, LO>), dim3(groups * 8 * Z), dim3(256), 0, st, W, X, out, N, K, ldx, (long)Mpad * N,
+                           GX, KS, Z, x_lo);
         return;
     }
     dim3 grid(GX, KS, Z);
-    hipLaunchKernelGGL((gemm_ldsx_kernel<T, MT, NT, NCH>), grid, dim3(256), 0, st, W, X, out, N, K, ldx, (long)Mpad * N, GX, KS, 1);
+    hipLaunchKernelGGL((gemm_ldsx_kernel<T, MT, NT, NCH, LO>), grid, dim3(256), 0, st, W, X, out, N, K, ldx, (long)Mpad * N, GX, KS, 1, x_lo);
 }
 
-template <typename T, int MT>
-static bool launch_ldsx_mt(hipStream_t st, const T* W, const T* X, float* out, int Mpad, int N, int K, int ldx, int NT, int NCH) {
-#define QTTS_LDSX(nt, nch) if (NT == nt && NCH == nch) { launch_ldsx<T, MT, nt, nch>(st, W, X, out, Mpad, N, K, ldx); return true; }
+template <typename T, int MT, bool LO>
+static bool launch_ldsx_mt(hipStream_t st, const T* W, const T* X, float* out, int Mpad, int N, int K, int ldx, int NT, int NCH, long x_lo) {
+#define QTTS_LDSX(nt, nch) if (NT == nt && NCH == nch) { launch_ldsx<T, MT, nt, nch, LO>(st, W, X, out, Mpad, N, K, ldx, x_lo); return true; }
     QTTS_LDSX(1, 4) QTTS_LDSX(1, 8) QTTS_LDSX(2, 4) QTTS_LDSX(2, 8)
-    if constexpr (MT <= 2) { QTTS_LDSX(1, 16) }
+    if constexpr (MT <= 2 && !LO) { QTTS_LDSX(1, 16) }
 #undef QTTS_LDSX
     return false;
 }
 
-template <typename T, int MT>
-static void launch_mt(hipStream_t st, const T* W, const T* X, float* out, int Mpad, int N, int K, int KS, int ldx) {
+template <typename T, int MT, bool LO>
+static void launch_mt(hipStream_t st, const T* W, const T* X, float* out, int Mpad, int N, int K, int KS, int ldx, long x_lo) {
     const int Z = Mpad / (16 * MT);
     const long kstride = (long)Mpad * N;
-    static const int dbg_nt = getenv("QTTS_GEMM_NT") ? atoi(getenv("QTTS_GEMM_NT")) : 0;
-    if (dbg_nt == 4 && N % 64 == 0) {
-        dim3 grid(N / 64, KS, Z);
-        hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 4>), grid, dim3(256), 0, st, W, X, out, N, K, KS, ldx, kstride);
-    } else if (N % 32 == 0 && (long)(N / 32) * KS * Z >= 256) {
+    if (N % 32 == 0 && (long)(N / 32) * KS * Z >= 256) {
         dim3 grid(N / 32, KS, Z);
-        hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 2>), grid, dim3(256), 0, st, W, X, out, N, K, KS, ldx, kstride);
+        hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 2, LO>), grid, dim3(256), 0, st, W, X, out, N, K, KS, ldx, kstride, x_lo);
     } else {
         dim3 grid(N / 16, KS, Z);
-        hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 1>), grid, dim3(256), 0, st, W, X, out, N, K, KS, ldx, kstride);
+        hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 1, LO>), grid, dim3(256), 0, st, W, X, out, N, K, KS, ldx, kstride, x_lo);
     }
 }
 
-template <typename T>
-static void launch_t(hipStream_t st, const T* W, const T* X, float* out, int Mpad, int N, int K, int KS, int ldx) {
-    if (Mpad == 16) launch_mt<T, 1>(st, W, X, out, Mpad, N, K, KS, ldx);
-    else if (Mpad == 32) launch_mt<T, 2>(st, W, X, out, Mpad, N, K, KS, ldx);
-    else launch_mt<T, 4>(st, W, X, out, Mpad, N, K, KS, ldx);
+template <typename T, bool LO>
+static void launch_t(hipStream_t st, const T* W, const T* X, float* out, int Mpad, int N, int K, int KS, int ldx, long x_lo) {
+    if (Mpad == 16) launch_mt<T, 1, LO>(st, W, X, out, Mpad, N, K, KS, ldx, x_lo);
+    else if (Mpad == 32) launch_mt<T, 2, LO>(st, W, X, out, Mpad, N, K, KS, ldx, x_lo);
+    else launch_mt<T, 4, LO>(st, W, X, out, Mpad, N, K, KS, ldx, x_lo);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -251,14 +308,15 @@ static void launch_t(hipStream_t st, const T* W, const T* X, float* out, int Mpa
 // taps of a causal conv are row offsets, so chunk cg reads X[(m + (cg / cpt) * tap_rows)][(cg % cpt) * CHUNK ...]
 // (cpt = chunks per tap).  A plain linear layer is the single-tap case.
 // With EPI the conv epilogue (conv_epi.hpp) runs on the accumulators in registers and no f32 output is written.
-template <typename T, int NT, int NCH, bool EPI>
+template <typename T, int NT, int NCH, bool EPI, bool LO>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(const T* __restrict__ W, const T* __restrict__ X,
                                                         float* __restrict__ out, int N, int K, int ldx, int cpt,
-                                                        long tap_stride, long row_base, ConvEpi e) {
+                                                        long tap_stride, long row_base, ConvEpi e, long x_lo) {
     using F = Frag<T>;
     constexpr int MT = 4;
     constexpr int HALF = 16 / sizeof(T);
-    __shared__ uint4 xs[NCH * MT * 2 * 64];
+    constexpr int NFB = NCH * MT * 2;
+    __shared__ uint4 xs[(LO ? 2 : 1) * NFB * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * (64 * NT) + wave * (16 * NT);
@@ -269,12 +327,12 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const T* __restrict__ W,
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    constexpr int NFB = NCH * MT * 2;
     for (int c0 = 0; c0 < nC; c0 += NCH) {
-        for (int fb = wave; fb < NFB; fb += 4) {
-            const int c = fb / (MT * 2), i = (fb >> 1) % MT, h = fb & 1;
+        for (int fb = wave; fb < (LO ? 2 : 1) * NFB; fb += 4) {
+            const int pl = fb / NFB, f = fb % NFB;
+            const int c = f / (MT * 2), i = (f >> 1) % MT, h = f & 1;
             const int cg = c0 + c;
-            const T* src = X + (row0 + 16 * i + r) * ldx + (long)(cg / cpt) * tap_stride + (long)(cg % cpt) * F::CHUNK +
+            const T* src = X + (pl ? x_lo : 0) + (row0 + 16 * i + r) * ldx + (long)(cg / cpt) * tap_stride + (long)(cg % cpt) * F::CHUNK +
                            g * F::EPL + h * HALF;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(xs + fb * 64), 16, 0, 0);
@@ -298,6 +356,14 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const T* __restrict__ W,
                 __builtin_memcpy((char*)&b + 16, &h1, 16);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[c][j], b, acc[i][j]);
+                if constexpr (LO) {
+                    const uint4 l0 = xs[(NFB + (c * MT + i) * 2 + 0) * 64 + lane];
+                    const uint4 l1 = xs[(NFB + (c * MT + i) * 2 + 1) * 64 + lane];
+                    __builtin_memcpy(&b, &l0, 16);
+                    __builtin_memcpy((char*)&b + 16, &l1, 16);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[c][j], b, acc[i][j]);
+                }
             }
         }
         __syncthreads();
@@ -325,9 +391,9 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const T* __restrict__ W,
             *reinterpret_cast<f32x4_t*>(out + (size_t)(row0 - row_base + 16 * i + r) * N + n0 + 16 * j + 4 * g) = acc[i][j];
 }
 
-template <typename T, bool EPI>
+template <typename T, bool EPI, bool LO = false>
 static void launch_rows_t(hipStream_t st, const T* W, const T* X, float* out, long Mpad, int N, int K, int ldx, int cpt, long tap_stride,
-                          const ConvEpi& e) {
+                          const ConvEpi& e, long x_lo = 0) {
     const int nC = K / Frag<T>::CHUNK;
     // out rows are relative to the launch: split launches at the grid.y limit
     for (long base = 0; base < Mpad; base += 65535L * 64) {
@@ -335,8 +401,8 @@ static void launch_rows_t(hipStream_t st, const T* W, const T* X, float* out, lo
         float* o = EPI ? nullptr : out + (size_t)base * N;
         const int gy = (int)(rows / 64);
 #define QTTS_ROWS(nt, nch)                                                                                                          \
-    hipLaunchKernelGGL((gemm_rows_kernel<T, nt, nch, EPI>), dim3(N / (64 * nt), gy), dim3(256), 0, st, W, X, o, N, K, ldx, cpt, \
-                       tap_stride, base, e)
+    hipLaunchKernelGGL((gemm_rows_kernel<T, nt, nch, EPI, LO>), dim3(N / (64 * nt), gy), dim3(256), 0, st, W, X, o, N, K, ldx, cpt, \
+                       tap_stride, base, e, x_lo)
         if (N % 128 == 0) {
             if (nC % 4 == 0) QTTS_ROWS(2, 4);
             else if (nC % 3 == 0) QTTS_ROWS(2, 3);
@@ -354,14 +420,16 @@ static void launch_rows_t(hipStream_t st, const T* W, const T* X, float* out, lo
 
 // out[m][n] = sum over taps/channels; M rows padded up to 64 must be readable in X (including the tap offsets).
 void launch_gemm_rows(hipStream_t st, int dtype, const void* W, const void* X, float* out, long M, int N, int K, int ldx, int taps,
-                      long tap_stride) {
+                      long tap_stride, long x_lo) {
     QTTS_CHECK(M >= 1 && N % 64 == 0 && taps >= 1 && K % taps == 0, ERR_SHAPE, "gemm_rows: N must be a multiple of 64");
     const int chunk = dtype == BF16 ? 64 : 32;
     QTTS_CHECK((K / taps) % chunk == 0, ERR_SHAPE, "gemm_rows: channels per tap must be a multiple of the K chunk");
     const long Mpad = (M + 63) / 64 * 64;
     const int cpt = K / taps / chunk;
     const ConvEpi none{};
-    if (dtype == BF16) launch_rows_t<bf16_t, false>(st, (const bf16_t*)W, (const bf16_t*)X, out, Mpad, N, K, ldx, cpt, tap_stride, none);
+    QTTS_CHECK(x_lo == 0 || dtype == BF16, ERR_BAD_ARG, "gemm_rows: a remainder plane exists for bf16 activations only");
+    if (dtype == BF16 && x_lo) launch_rows_t<bf16_t, false, true>(st, (const bf16_t*)W, (const bf16_t*)X, out, Mpad, N, K, ldx, cpt, tap_stride, none, x_lo);
+    else if (dtype == BF16) launch_rows_t<bf16_t, false>(st, (const bf16_t*)W, (const bf16_t*)X, out, Mpad, N, K, ldx, cpt, tap_stride, none);
     else launch_rows_t<float, false>(st, (const float*)W, (const float*)X, out, Mpad, N, K, ldx, cpt, tap_stride, none);
 }
 
@@ -376,8 +444,7 @@ void launch_gemm_rows_epi(hipStream_t st, int dtype, const void* W, const void* 
     QTTS_CHECK(e.out2 == nullptr || e.act2 == 1 || (e.alpha_exp && e.beta_den), ERR_BAD_ARG, "gemm_rows: snake output without parameters");
     const int chunk = dtype == BF16 ? 64 : 32;
     QTTS_CHECK((K / taps) % chunk == 0, ERR_SHAPE, "gemm_rows: channels per tap must be a multiple of the K chunk");
-    static const bool halo_off = getenv("QTTS_CONV_HALO") && atoi(getenv("QTTS_CONV_HALO")) == 0;
-    if (!halo_off && launch_conv_halo(st, dtype, W, X, K, ldx, taps, tap_stride, e)) return;
+    if (!gemm_env().conv_halo_off && launch_conv_halo(st, dtype, W, X, K, ldx, taps, tap_stride, e)) return;
     const long Mpad = (M + 63) / 64 * 64;
     const int cpt = K / taps / chunk;
     if (dtype == BF16) launch_rows_t<bf16_t, true>(st, (const bf16_t*)W, (const bf16_t*)X, nullptr, Mpad, N, K, ldx, cpt, tap_stride, e);
@@ -389,12 +456,11 @@ int gemm_pad_rows(int M) { return M <= 16 ? 16 : (M <= 32 ? 32 : (M + 63) / 64 *
 // Picks the kernel variant and the split-K factor for a shape.  Deterministic in (M, N, K, dtype) so that the
 // consumers of the partial slabs can recompute KS.
 GemmPlan gemm_plan(int M, int N, int K, int dtype) {
-    static const int force_kind = getenv("QTTS_GEMM_KIND") ? atoi(getenv("QTTS_GEMM_KIND")) : -1;
-    static const int force_nt = getenv("QTTS_GEMM_NT") ? atoi(getenv("QTTS_GEMM_NT")) : 0;
-    static const int force_nch = getenv("QTTS_GEMM_NCH") ? atoi(getenv("QTTS_GEMM_NCH")) : 0;
+    const GemmEnv& env = gemm_env();
+    const int force_kind = env.force_kind, force_nt = env.force_nt, force_nch = env.force_nch;
     // first candidate (fewest slabs first) that still gives this many blocks: 192 measured best (fewer slab bytes to write and
     // read back; with several batches in flight the other streams fill the CUs a smaller grid leaves idle)
-    static const int min_blocks = getenv("QTTS_GEMM_MIN_BLOCKS") ? atoi(getenv("QTTS_GEMM_MIN_BLOCKS")) : 192;
+    const int min_blocks = env.min_blocks;
     const int chunk = dtype == BF16 ? 64 : 32;
     const int nC = K / chunk;
     const int Mpad = gemm_pad_rows(M);
@@ -430,27 +496,29 @@ GemmPlan gemm_plan(int M, int N, int K, int dtype) {
 
 int gemm_pick_ks(int M, int N, int K, int dtype) { return gemm_plan(M, N, K, dtype).KS; }
 
-template <typename T>
-static void launch_plan(hipStream_t st, const GemmPlan& p, const T* W, const T* X, float* out, int Mpad, int N, int K, int ldx) {
+template <typename T, bool LO>
+static void launch_plan(hipStream_t st, const GemmPlan& p, const T* W, const T* X, float* out, int Mpad, int N, int K, int ldx, long x_lo) {
     if (p.kind == 1) {
         bool ok = false;
-        if (Mpad == 32) ok = launch_ldsx_mt<T, 2>(st, W, X, out, Mpad, N, K, ldx, p.NT, p.NCH);
-        else ok = launch_ldsx_mt<T, 4>(st, W, X, out, Mpad, N, K, ldx, p.NT, p.NCH);
+        if (Mpad == 32) ok = launch_ldsx_mt<T, 2, LO>(st, W, X, out, Mpad, N, K, ldx, p.NT, p.NCH, x_lo);
+        else ok = launch_ldsx_mt<T, 4, LO>(st, W, X, out, Mpad, N, K, ldx, p.NT, p.NCH, x_lo);
         QTTS_CHECK(ok, ERR_STATE, "gemm: no kernel instance for the planned variant");
         return;
     }
-    launch_t<T>(st, W, X, out, Mpad, N, K, p.KS, ldx);
+    launch_t<T, LO>(st, W, X, out, Mpad, N, K, p.KS, ldx, x_lo);
 }
 
-void launch_gemm(hipStream_t st, int dtype, const void* W, const void* X, float* out, int M, int N, int K, int KS, int ldx) {
+void launch_gemm(hipStream_t st, int dtype, const void* W, const void* X, float* out, int M, int N, int K, int KS, int ldx, long x_lo) {
     QTTS_CHECK(N % 16 == 0, ERR_SHAPE, "gemm: N must be a multiple of 16");
     QTTS_CHECK(K % 64 == 0, ERR_SHAPE, "gemm: K must be a multiple of 64");
     QTTS_CHECK(KS >= 1 && M >= 1, ERR_SHAPE, "gemm: bad M/KS");
+    QTTS_CHECK(x_lo == 0 || dtype == BF16, ERR_BAD_ARG, "gemm: a remainder plane exists for bf16 activations only");
     const int Mpad = gemm_pad_rows(M);
     GemmPlan p = gemm_plan(M, N, K, dtype);
     if (p.KS != KS) p = GemmPlan{KS, 0, 1, 0};  // caller forced a split factor: generic kernel
-    if (dtype == BF16) launch_plan<bf16_t>(st, p, (const bf16_t*)W, (const bf16_t*)X, out, Mpad, N, K, ldx);
-    else launch_plan<float>(st, p, (const float*)W, (const float*)X, out, Mpad, N, K, ldx);
+    if (dtype == BF16 && x_lo) launch_plan<bf16_t, true>(st, p, (const bf16_t*)W, (const bf16_t*)X, out, Mpad, N, K, ldx, x_lo);
+    else if (dtype == BF16) launch_plan<bf16_t, false>(st, p, (const bf16_t*)W, (const bf16_t*)X, out, Mpad, N, K, ldx, 0);
+    else launch_plan<float, false>(st, p, (const float*)W, (const float*)X, out, Mpad, N, K, ldx, 0);
 }
 
 }  // namespace qtts

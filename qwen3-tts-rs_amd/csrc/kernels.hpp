@@ -30,34 +30,14 @@ int gemm_pad_rows(int M);
 GemmPlan gemm_plan(int M, int N, int K, int dtype);
 int gemm_pick_ks(int M, int N, int K, int dtype);
 // out is [KS][gemm_pad_rows(M)][N] f32 partial sums; X has gemm_pad_rows(M) readable rows of ldx elements.
-void launch_gemm(hipStream_t st, int dtype, const void* W, const void* X, float* out, int M, int N, int K, int KS, int ldx);
+// x_lo != 0 (bf16 only): X carries a remainder plane x_lo elements behind it and both planes are multiplied, so that the
+// activations enter the product with about 16 significant bits (the weights stay plain bf16).
+void launch_gemm(hipStream_t st, int dtype, const void* W, const void* X, float* out, int M, int N, int K, int KS, int ldx,
+                 long x_lo = 0);
 // Large-M GEMM with convolution addressing: out[m][n] = sum_{tap, c} X[m*ldx + tap*tap_stride + c] * W[n][tap*C + c], C = K / taps.
 // out is [ceil64(M)][N] f32; X must be readable for ceil64(M) rows plus the tap offsets.
 void launch_gemm_rows(hipStream_t st, int dtype, const void* W, const void* X, float* out, long M, int N, int K, int ldx, int taps,
-                      long tap_stride);
-
-// ---- k_gemm_fused.hip: decode-path GEMM (one block per output tile, full K) with the consumer's epilogue fused in
-enum { GEMM_EPI_PLAIN = 0, GEMM_EPI_RESID = 1, GEMM_EPI_SWIGLU = 2 };
-struct GemmEpi {
-    int mode;
-    const float* ss_in;    // optional [ntiles_in][ss_ld]: per-row partial sums of squares of the input's f32 source
-    long ss_ld;            // row stride of ss_in / ss_out
-    int ntiles_in, H_in;   // row scale = 1 / sqrt(sum_t ss_in[t][m] / H_in + eps)
-    float eps;
-    const float* bias;     // [N] or null
-    float* out_f32;        // PLAIN: [rows][ld_out]
-    int ld_out;
-    const float* resid;    // RESID: optional [rows][N] f32 (may alias x_out)
-    float* x_out;          // RESID: [rows][N] f32
-    void* xb_out;          // RESID: [rows][N] model dtype = x * nw
-    const float* nw;       // RESID: optional [N] norm weight of the consumer
-    float* ss_out;         // RESID: optional [gemm_fused_ntiles][ss_ld]
-    void* act;             // SWIGLU: [rows][N/2] model dtype
-};
-int gemm_fused_rows(int M);
-int gemm_fused_ntiles(int M, int N, int mode);  // tiles a RESID launch writes to ss_out
-// X: [rows][ldx] model dtype.  W rows for SWIGLU are interleaved: every 32 rows = 16 gate rows then the matching 16 up rows.
-void launch_gemm_fused(hipStream_t st, int dtype, const void* W, const void* X, int ldx, int M, int N, int K, const GemmEpi& e);
+                      long tap_stride, long x_lo = 0);
 
 // ---- k_bench.hip (diagnostics)
 void launch_stream(hipStream_t st, const void* src, unsigned* sink, long bytes, int blocks, int pattern, int unroll, int ld_bytes);
@@ -71,14 +51,15 @@ void launch_chain_b(hipStream_t st, const float* in, float* out, int n, int bloc
 // x = [resid] + [scale *] (sum_ks part[ks] + [bias]); resid_out = x (f32, may alias resid); xn = rmsnorm(x) * w -> dtype;
 // xn_f32 (optional) receives the same normalised row in f32.
 // `scale` (optional, per channel) multiplies (sum part + bias) before the residual add (LayerScale).
+// Every `*_lo` argument below: element offset of the output's remainder plane (see launch_gemm), 0 = none.
 void launch_resid_norm(hipStream_t st, int dtype, const float* resid, const float* part, int KS, long ks_stride,
                        const float* bias, const float* scale, const float* norm_w, float eps, float* resid_out, void* xn,
-                       float* xn_f32, int M, int H);
+                       float* xn_f32, int M, int H, long xn_lo = 0);
 // act = silu(sum part[..][0:I]) * sum part[..][I:2I] -> dtype   (candle_nn::ops::swiglu)
-void launch_swiglu(hipStream_t st, int dtype, const float* part, int KS, long ks_stride, void* act, int M, int I);
+void launch_swiglu(hipStream_t st, int dtype, const float* part, int KS, long ks_stride, void* act, int M, int I, long act_lo = 0);
 // out = act(sum_ks part + bias): act 0 none, 1 silu, 2 erf-GELU; out_dtype F32/BF16 independent of the weight dtype
 void launch_bias_act(hipStream_t st, const float* part, int KS, long ks_stride, const float* bias, int act, void* out,
-                     int out_dtype, int M, int N);
+                     int out_dtype, int M, int N, long out_lo = 0);
 // dst[i][:] = table[idx[i]][:]  (table in `tdtype`, dst in `ddtype`)
 void launch_gather_rows(hipStream_t st, const void* table, int tdtype, const int* idx, void* dst, int ddtype, int M, int H,
                         long dst_ld);
@@ -100,12 +81,8 @@ struct EmbedSumArgs {
     const float* tts_pad;           // [H] f32
     int G, H, B;
 };
-// ss_out != null selects the split norm: xn = T(x * norm_w) and ss_out[b] = sum x^2 (the consuming GEMM applies 1/rms)
 void launch_embed_sum_norm(hipStream_t st, int dtype, const EmbedSumArgs& a, const float* norm_w, float eps, float* resid_out,
-                           void* xn, float* ss_out = nullptr);
-void launch_rows_prep(hipStream_t st, int dtype, const float* x, const float* nw, float* x_out, void* xb, float* ss_out, int M, int H);
-void launch_norm_rows(hipStream_t st, int dtype, const float* x, const float* ss, int ntiles, long ss_ld, const float* nw, float eps,
-                      void* out, float* out_f32, int M, int H);
+                           void* xn, long xn_lo = 0);
 // code-predictor input rows: dst[b] = table[codes[b][g]] cast to dtype (codes laid out as in EmbedSumArgs)
 void launch_gather_codes(hipStream_t st, const void* table, int tdtype, const unsigned* codes_base, long row_stride,
                          const int* step, int G, int g, void* dst, int ddtype, int B, int H);
@@ -138,11 +115,11 @@ struct QkvPostArgs {
 void launch_qkv_post(hipStream_t st, int dtype, const QkvPostArgs& a, const KVView& kv);
 // softmax(q k^T * scale over the token's key range) v  -> out [Mpad][nh d] in dtype
 void launch_attention(hipStream_t st, int dtype, const float* q, const Tok* toks, const KVView& kv, int layer, int M, int nh,
-                      float scale, void* out);
+                      float scale, void* out, long out_lo = 0);
 
 // qkv_post + attention in one launch for decode steps: every token's newest key is its own position and no other token
 // of the launch attends to it
-void launch_attention_decode(hipStream_t st, int dtype, const QkvPostArgs& a, const KVView& kv, float scale, void* out);
+void launch_attention_decode(hipStream_t st, int dtype, const QkvPostArgs& a, const KVView& kv, float scale, void* out, long out_lo = 0);
 
 // ---- k_sample.hip
 struct SampleArgs {

@@ -211,7 +211,7 @@ void Model::ensure_rope(StackW& s, int max_pos) {
     s.max_pos = n;
 }
 
-void build_stack(Model& m, StackW& s, const StackCfg& c, const std::string& prefix, bool qk_norm, bool layer_scale, bool interleaved_mlp) {
+void build_stack(Model& m, StackW& s, const StackCfg& c, const std::string& prefix, bool qk_norm, bool layer_scale) {
     s.cfg = c;
     s.layers.resize((size_t)c.layers);
     const size_t es = dtype_size(m.dtype);
@@ -238,16 +238,6 @@ void build_stack(Model& m, StackW& s, const StackCfg& c, const std::string& pref
         gu.alloc((size_t)2 * c.inter * c.hidden * es);
         QTTS_HIP(hipMemcpyAsync(gu.p, m.mat(p + "mlp.gate_proj.weight"), (size_t)c.inter * c.hidden * es, hipMemcpyDeviceToDevice, st));
         QTTS_HIP(hipMemcpyAsync((char*)gu.p + (size_t)c.inter * c.hidden * es, m.mat(p + "mlp.up_proj.weight"), (size_t)c.inter * c.hidden * es, hipMemcpyDeviceToDevice, st));
-        if (interleaved_mlp) {
-            QTTS_CHECK(c.inter % 16 == 0, ERR_SHAPE, "intermediate size must be a multiple of 16");
-            DevBuf il;
-            il.alloc((size_t)2 * c.inter * c.hidden * es);
-            const size_t grp = (size_t)16 * c.hidden * es;
-            QTTS_HIP(hipMemcpy2DAsync(il.p, 2 * grp, m.mat(p + "mlp.gate_proj.weight"), grp, grp, (size_t)c.inter / 16, hipMemcpyDeviceToDevice, st));
-            QTTS_HIP(hipMemcpy2DAsync((char*)il.p + grp, 2 * grp, m.mat(p + "mlp.up_proj.weight"), grp, grp, (size_t)c.inter / 16, hipMemcpyDeviceToDevice, st));
-            w.gate_up_il = il.p;
-            m.owned.push_back(std::move(il));
-        }
         w.qkv = qkv.p;
         w.gate_up = gu.p;
         m.owned.push_back(std::move(qkv));
@@ -290,8 +280,8 @@ void Model::finalize() {
     QTTS_HIP(hipSetDevice(ctx->device));
     const bool have_talker = has("talker.model.norm.weight");
     if (have_talker) {
-        build_stack(*this, talker, cfg.talker, "talker.model.", true, false, true);
-        build_stack(*this, cp, cfg.cp, "talker.code_predictor.model.", true, false, true);
+        build_stack(*this, talker, cfg.talker, "talker.model.", true, false);
+        build_stack(*this, cp, cfg.cp, "talker.code_predictor.model.", true, false);
         const int H = cfg.talker.hidden, Ht = cfg.text_hidden, Hc = cfg.cp.hidden, G = cfg.groups;
         expect_shape(get("talker.model.codec_embedding.weight"), "talker.model.codec_embedding.weight", {cfg.vocab, H});
         expect_shape(get("talker.model.text_embedding.weight"), "talker.model.text_embedding.weight", {cfg.text_vocab, Ht});

@@ -101,7 +101,6 @@ struct CodecCfg {  // audio/decoder/config.rs
 
 struct LayerW {
     const void *qkv = nullptr, *o = nullptr, *gate_up = nullptr, *down = nullptr;  // model dtype
-    const void* gate_up_il = nullptr;  // gate|up interleaved in 16-row groups (fused SwiGLU epilogue), decode stacks only
     const float *qkv_bias = nullptr, *o_bias = nullptr, *q_norm = nullptr, *k_norm = nullptr, *ln1 = nullptr, *ln2 = nullptr;
     const float *ls_attn = nullptr, *ls_mlp = nullptr;  // LayerScale (codec transformer only)
 };
@@ -153,8 +152,7 @@ struct Model {
 };
 
 // Fuses q|k|v and gate|up of every layer under `prefix` and fills the per-layer weight table.
-void build_stack(Model& m, StackW& s, const StackCfg& c, const std::string& prefix, bool qk_norm, bool layer_scale,
-                 bool interleaved_mlp = false);
+void build_stack(Model& m, StackW& s, const StackCfg& c, const std::string& prefix, bool qk_norm, bool layer_scale);
 
 // cos/sin tables on the host exactly as the reference computes them
 void rope_table_default(int d, double theta, int max_pos, std::vector<float>& cos, std::vector<float>& sin);  // rope/core.rs:150-160
