@@ -122,6 +122,9 @@ typedef struct {
     /* Throughput-measurement protocol (no counterpart in the reference): when > 0, overrides qtts_sampling.min_new_tokens so
      * that every row of a benchmark run produces the same fixed length. */
     int min_new_tokens;
+    /* Optional trace of the code predictor's logits (eager launches only, like logits / hidden):
+     * [n][max_new][num_code_groups - 1][code predictor vocab]. */
+    float* cp_logits;
 } qtts_gen_debug;
 
 /* ConditionalGeneration::generate (nn/generation.rs:815-1194) for n independent utterances decoded as

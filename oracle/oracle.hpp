@@ -133,6 +133,7 @@ enum MaskMode { MASK_NONE = 0, MASK_CAUSAL = 1 };
 // (nn/decoder_layer.rs:63-86, nn/attention/unified.rs:179-243, nn/attention/mod.rs:359-472,
 // nn/mlp.rs:59-82).  x is [T][hidden], updated in place.
 void set_round_probe(int mask);  // diagnostic: see oracle_tts.cpp
+void probe_round(float* x, size_t n, int bit);
 void decoder_layer(const Weights& w, const std::string& prefix, const AttnShape& a, const RopeTable& rope,
                    float* x, int T, int pos0, MaskMode mask, KVCacheLayer& cache);
 

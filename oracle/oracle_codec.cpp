@@ -216,8 +216,10 @@ void CodecModel::convnext(std::vector<float>& x, int C, int T, const std::string
         float den = std::sqrt(var + 1e-6f);
         for (int c = 0; c < C; ++c) rows[(size_t)t * C + c] = (y[(size_t)c * T + t] - mean) / den * lw[c] + lb[c];
     }
+    probe_round(rows.data(), rows.size(), 12);
     linear(rows.data(), W(w, p + "pwconv1.weight").p(), W(w, p + "pwconv1.bias").p(), h1.data(), T, 4 * C, C);
     for (auto& v : h1) v = gelu_tanh(v);
+    probe_round(h1.data(), h1.size(), 13);
     linear(h1.data(), W(w, p + "pwconv2.weight").p(), W(w, p + "pwconv2.bias").p(), h2.data(), T, C, 4 * C);
     const float* gm = W(w, p + "gamma").p();
     for (int c = 0; c < C; ++c)
@@ -254,9 +256,11 @@ void CodecModel::decode(const uint32_t* codes, int T, std::vector<float>& wav, C
             for (int i = 0; i < Dc; ++i) x[(size_t)i * T + t] = o1[(size_t)t * Dc + i];
     }
     if (trace) trace->after_quantizer = x;
+    probe_round(x.data(), x.size(), 8);
     std::vector<float> y;
     causal_conv1d(x, Dc, T, W(w, "decoder.pre_conv.conv.weight"), W(w, "decoder.pre_conv.conv.bias").p(), 1, 1, y);
     if (trace) trace->after_pre_conv = y;
+    probe_round(y.data(), y.size(), 9);
     // transformer on [T][latent]
     std::vector<float> seq((size_t)T * c.latent);
     for (int ch = 0; ch < c.latent; ++ch)
@@ -266,6 +270,7 @@ void CodecModel::decode(const uint32_t* codes, int T, std::vector<float>& wav, C
     for (int ch = 0; ch < c.latent; ++ch)
         for (int t = 0; t < T; ++t) x[(size_t)ch * T + t] = seq[(size_t)t * c.latent + ch];
     if (trace) trace->after_transformer = x;
+    probe_round(x.data(), x.size(), 10);
     int Tc = T, C = c.latent;
     for (size_t i = 0; i < c.upsampling_ratios.size(); ++i) {
         const std::string p = "decoder.upsample." + std::to_string(i) + ".";
@@ -273,7 +278,9 @@ void CodecModel::decode(const uint32_t* codes, int T, std::vector<float>& wav, C
         causal_conv_transpose1d(x, C, Tc, W(w, p + "0.conv.weight"), W(w, p + "0.conv.bias").p(), c.upsampling_ratios[i], y, To);
         x.swap(y);
         Tc = To;
+        probe_round(x.data(), x.size(), 11);
         convnext(x, C, Tc, p + "1.");
+        probe_round(x.data(), x.size(), 14);
     }
     if (trace) trace->after_upsample = x;
     causal_conv1d(x, C, Tc, W(w, "decoder.decoder.0.conv.weight"), W(w, "decoder.decoder.0.conv.bias").p(), 1, 1, y);
@@ -282,6 +289,8 @@ void CodecModel::decode(const uint32_t* codes, int T, std::vector<float>& wav, C
     for (size_t b = 0; b < c.upsample_rates.size(); ++b) {  // DecoderBlock (residual_unit.rs:47-96)
         const std::string p = "decoder.decoder." + std::to_string(b + 1) + ".block.";
         snake_beta(x, C, Tc, W(w, p + "0.alpha"), W(w, p + "0.beta"));
+        probe_round(x.data(), x.size(), 15);
+        probe_round(x.data(), x.size(), 19 + (int)b);
         int To;
         causal_conv_transpose1d(x, C, Tc, W(w, p + "1.conv.weight"), W(w, p + "1.conv.bias").p(), c.upsample_rates[b], y, To);
         x.swap(y);
@@ -292,8 +301,10 @@ void CodecModel::decode(const uint32_t* codes, int T, std::vector<float>& wav, C
             const std::string q = p + std::to_string(u + 2) + ".";
             std::vector<float> hcur(x);
             snake_beta(hcur, C, Tc, W(w, q + "act1.alpha"), W(w, q + "act1.beta"));
+            probe_round(hcur.data(), hcur.size(), 16);
             causal_conv1d(hcur, C, Tc, W(w, q + "conv1.conv.weight"), W(w, q + "conv1.conv.bias").p(), dils[u], 1, y);
             snake_beta(y, C, Tc, W(w, q + "act2.alpha"), W(w, q + "act2.beta"));
+            probe_round(y.data(), y.size(), 17);
             causal_conv1d(y, C, Tc, W(w, q + "conv2.conv.weight"), W(w, q + "conv2.conv.bias").p(), 1, 1, hcur);
             for (size_t i = 0; i < x.size(); ++i) x[i] = x[i] + hcur[i];
         }
@@ -302,6 +313,7 @@ void CodecModel::decode(const uint32_t* codes, int T, std::vector<float>& wav, C
     const int nb = (int)c.upsample_rates.size();
     snake_beta(x, C, Tc, W(w, "decoder.decoder." + std::to_string(nb + 1) + ".alpha"),
                W(w, "decoder.decoder." + std::to_string(nb + 1) + ".beta"));
+    probe_round(x.data(), x.size(), 18);
     causal_conv1d(x, C, Tc, W(w, "decoder.decoder." + std::to_string(nb + 2) + ".conv.weight"),
                   W(w, "decoder.decoder." + std::to_string(nb + 2) + ".conv.bias").p(), 1, 1, y);
     wav.resize((size_t)Tc);

@@ -210,10 +210,10 @@ void RopeTable::cos_sin(int64_t pos, float* c, float* s) const {
 // -------------------------------------------------------------------------- decoder layer
 // Diagnostic only (0 in every parity check): rounds the named intermediate tensors to bf16 so that the storage precision of
 // a reduced-precision implementation can be priced tensor by tensor.  bit 0: normed layer inputs, bit 1: keys / values,
-// bit 2: attention output, bit 3: MLP activation.
+// bit 2: attention output, bit 3: MLP activation; bits 8-18: tensors of the codec decoder (oracle_codec.cpp).
 static int g_round_probe = 0;
 void set_round_probe(int mask) { g_round_probe = mask; }
-static void probe_round(float* x, size_t n, int bit) {
+void probe_round(float* x, size_t n, int bit) {
     if (!(g_round_probe & (1 << bit))) return;
     for (size_t i = 0; i < n; ++i) {
         uint32_t u;

@@ -196,11 +196,13 @@ struct Geometry {
     std::vector<long> Tmax, S;
     std::vector<int> P;
     size_t act_elems = 0, acc_elems = 0, res_elems = 0;
+    size_t lo_elems = 0;  // largest tensor that carries a remainder plane in bf16 runs (the low-rate stages)
     long wav_max = 0;
-    size_t bytes(size_t es) const { return act_elems * es * 3 + (acc_elems + res_elems) * 4 + (size_t)U * (size_t)wav_max * 4; }
+    size_t bytes(size_t es) const { return (act_elems + lo_elems) * es * 3 + (acc_elems + res_elems) * 4 + (size_t)U * (size_t)wav_max * 4; }
 };
 
 constexpr long SLACK_ROWS = CONV_HALO_SLACK + 64;  // readable rows past the last strip: 64-row GEMM tile padding + tap offsets
+constexpr int SPLIT_BLOCKS = 2;  // vocoder blocks whose transposed conv reads an input with a remainder plane (bf16 runs)
 
 Geometry make_geometry(const CodecCfg& c, const CodecState& s, int U, int Tm) {
     Geometry g;
@@ -223,19 +225,23 @@ Geometry make_geometry(const CodecCfg& c, const CodecState& s, int U, int Tm) {
         g.P[(size_t)i + 1] = s.maxpad;
     }
     for (int i = 0; i < g.nstage; ++i) g.S[(size_t)i] = g.P[(size_t)i] + g.Tmax[(size_t)i];
-    auto need = [&](long rows, int width) { g.act_elems = std::max(g.act_elems, (size_t)(rows + SLACK_ROWS) * (size_t)width); };
+    auto need = [&](long rows, int width, bool split = false) {
+        g.act_elems = std::max(g.act_elems, (size_t)(rows + SLACK_ROWS) * (size_t)width);
+        if (split) g.lo_elems = std::max(g.lo_elems, (size_t)(rows + SLACK_ROWS) * (size_t)width);
+    };
     auto need_acc = [&](long M, int N) { g.acc_elems = std::max(g.acc_elems, (size_t)((M + 63) / 64 * 64) * (size_t)N); };
     const long M0 = U * g.S[0];
-    need(M0, std::max({s.DcP, s.latP}));
+    need(M0, std::max({s.DcP, s.latP}), true);
     need_acc(M0, s.latP);
     for (int i = 0; i < g.nup; ++i) {
         const long Mout = U * g.S[(size_t)i + 1];
         need(Mout, s.ups[(size_t)i].pw1.CoutP);
+        need(Mout, s.latP, true);
     }
-    need(U * g.S[(size_t)g.nup], s.dec0.CoutP);
+    need(U * g.S[(size_t)g.nup], s.dec0.CoutP, true);
     for (int b = 0; b < g.nb; ++b) {
         const long Mout = U * g.S[(size_t)g.nup + b + 1];
-        need(Mout, s.blocks[(size_t)b].ct.CoutP);
+        need(Mout, s.blocks[(size_t)b].ct.CoutP, b + 1 < SPLIT_BLOCKS);
         g.res_elems = std::max(g.res_elems, (size_t)(Mout + SLACK_ROWS) * (size_t)s.blocks[(size_t)b].ct.CoutP);
     }
     g.wav_max = g.Tmax[(size_t)g.nstage - 1];
@@ -258,8 +264,9 @@ struct Decoder {
         const void* X = nullptr;
         long M = 0;
         int ldx = 0;
+        long x_lo = 0;  // remainder plane of X (bf16 runs, the low-rate stages)
     } pend;
-    void gemm(const GemmW& g, const void* X, long M, int ldx) { pend = Pending{&g, X, M, ldx}; }
+    void gemm(const GemmW& g, const void* X, long M, int ldx, long x_lo = 0) { pend = Pending{&g, X, M, ldx, x_lo}; }
     // QTTS_CODEC_PROFILE=1: HIP events around every conv launch, one table per group on stderr (measurement aid)
     struct Prof {
         hipEvent_t a, b;
@@ -278,7 +285,7 @@ struct Decoder {
             QTTS_HIP(hipEventCreate(&pr.b));
             QTTS_HIP(hipEventRecord(pr.a, st));
         }
-        launch_gemm_rows_epi(st, dt, pend.g->w.p, pend.X, pend.g->K, pend.ldx, pend.g->taps, (long)pend.g->dil * pend.ldx, e);
+        launch_gemm_rows_epi(st, dt, pend.g->w.p, pend.X, pend.g->K, pend.ldx, pend.g->taps, (long)pend.g->dil * pend.ldx, e, pend.x_lo);
         if (profiling) {
             QTTS_HIP(hipEventRecord(pr.b, st));
             prof.push_back(pr);
@@ -349,13 +356,21 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
 
     // Only the leading rows of every strip (the causal padding the next conv reads) must be zero: rows past a strip's valid
     // length are never read by a valid row, and whatever a tile computes from them is masked in the epilogue.
-    auto zero_pad_rows = [&](void* buf, long S_rows, int P_rows, int C) {
-        if (P_rows > 0)
+    // bf16 runs keep a remainder plane (see launch_gemm) behind every activation buffer and use it for the tensors of the
+    // low-rate stages - everything up to the second vocoder block's transposed conv - where bf16 rounding of the activations
+    // is what limits the waveform SNR (each of them alone costs 42-46 dB; the high-rate vocoder tensors 49 dB and more).
+    // Their convs run through the tap-addressed GEMM with both planes; these stages are a few percent of the decoder's FLOPs.
+    const long lo = split_activations(dt) ? (long)g.act_elems : 0;
+    auto zero_pad_rows = [&](void* buf, long S_rows, int P_rows, int C, bool both = false) {
+        if (P_rows > 0) {
             QTTS_HIP(hipMemset2DAsync(buf, (size_t)S_rows * C * es, 0, (size_t)P_rows * C * es, (size_t)U, st));
+            if (both && lo)
+                QTTS_HIP(hipMemset2DAsync((char*)buf + (size_t)lo * es, (size_t)S_rows * C * es, 0, (size_t)P_rows * C * es, (size_t)U, st));
+        }
     };
-    s.A.ensure(g.act_elems * es);
-    s.Bf.ensure(g.act_elems * es);
-    s.R.ensure(g.act_elems * es);
+    s.A.ensure((g.act_elems + (lo ? g.lo_elems : 0)) * es);
+    s.Bf.ensure((g.act_elems + (lo ? g.lo_elems : 0)) * es);
+    s.R.ensure((g.act_elems + (lo ? g.lo_elems : 0)) * es);
     s.Rf.ensure(g.res_elems * 4);  // the vocoder's residual stream is kept in f32
     s.acc.ensure(g.acc_elems * 4);
     s.wav.ensure((size_t)U * (size_t)g.wav_max * 4);
@@ -366,15 +381,17 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
     const long M0 = U * S[0];
     const int Hd = c.hidden;
     QTTS_HIP(hipMemsetAsync(s.A.p, 0, (size_t)(M0 + SLACK_ROWS) * s.DcP * es, st));
+    if (lo) QTTS_HIP(hipMemsetAsync((char*)s.A.p + (size_t)lo * es, 0, (size_t)(M0 + SLACK_ROWS) * s.DcP * es, st));
     launch_rvq_gather(st, dt, s.table.as<float>(), d_codes, d_meta + o_rows, d_meta + o_starts, d_len(0), U, Tm, s.Q, s.csize, s.DcP,
-                      T_max, S[0], P[0], s.A.p, s.DcP);
+                      T_max, S[0], P[0], s.A.p, s.DcP, lo);
     // pre_conv (k = 3): acc row (u, t) reads strip rows t .. t + 2 (two leading zero rows)
-    gemm(s.pre_conv, s.A.p, M0, s.DcP);
+    gemm(s.pre_conv, s.A.p, M0, s.DcP, lo);
     QTTS_HIP(hipMemsetAsync(s.Bf.p, 0, (size_t)(M0 + SLACK_ROWS) * s.latP * es, st));
+    if (lo) QTTS_HIP(hipMemsetAsync((char*)s.Bf.p + (size_t)lo * es, 0, (size_t)(M0 + SLACK_ROWS) * s.latP * es, st));
     {
         ConvEpi e{};
         e.M = M0; e.N = s.pre_conv.N; e.r = 1; e.Cout = s.pre_conv.CoutP; e.bias = s.pre_conv.bias.as<float>();
-        e.lens = d_len(0); e.S_in = S[0]; e.S_out = S[0]; e.P_out = 0; e.ld_out = s.latP; e.out = s.Bf.p;
+        e.lens = d_len(0); e.S_in = S[0]; e.S_out = S[0]; e.P_out = 0; e.ld_out = s.latP; e.out = s.Bf.p; e.out_lo = lo;
         epilogue(e);
     }
     // transformer over every strip row (rows past a strip's length are computed and ignored)
@@ -433,7 +450,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         Runner run(m, s.ws, nullptr);
         // input_proj (+bias) starts the residual stream
         int ks = run.ks_for(M, Hd, s.latP);
-        run.gemm(s.in_proj.w.p, s.Bf.p, M, Hd, s.latP, ks, s.latP);
+        run.gemm(s.in_proj.w.p, s.Bf.p, M, Hd, s.latP, ks, s.latP, lo);
         launch_resid_norm(st, dt, nullptr, s.ws.part.as<float>(), ks, run.kstride(M, Hd), s.in_proj.bias.as<float>(), nullptr,
                           s.xf.layers[0].ln1, c.eps, s.ws.x.as<float>(), s.ws.xn.p, nullptr, M, Hd, s.ws.lo_xn);
         run.stack(s.xf, M, s.toks.as<Tok>(), kv, s.ws.xn.p, nullptr, sc != nullptr, false, s.ws.lo_xn);
@@ -447,16 +464,19 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         }
         ConvEpi e{};
         e.acc = acc; e.M = M0; e.N = s.latP; e.r = 1; e.Cout = s.latP; e.bias = s.out_proj.bias.as<float>();
-        e.lens = d_len(0); e.S_in = S[0]; e.S_out = S[0]; e.P_out = 0; e.ld_out = s.latP; e.out = s.A.p;
+        e.lens = d_len(0); e.S_in = S[0]; e.S_out = S[0]; e.P_out = 0; e.ld_out = s.latP; e.out = s.A.p; e.out_lo = lo;
         launch_conv_epilogue(st, dt, e);
         if (sc) {
             // rows [0, C) of every strip: the transformer output of the previous pushes; then keep this push's tail
             const size_t rowb = (size_t)s.latP * es, strip = (size_t)S[0] * rowb, slot = (size_t)sc->ctx_cap * rowb;
-            if (Cs > 0)
-                QTTS_HIP(hipMemcpy2DAsync(s.A.p, strip, sc->latent_ctx.p, slot, (size_t)Cs * rowb, (size_t)U, hipMemcpyDeviceToDevice, st));
             const int keep = std::min(Tm, sc->ctx_cap);
-            QTTS_HIP(hipMemcpy2DAsync(sc->latent_ctx.p, slot, (const char*)s.A.p + (size_t)(Tm - keep) * rowb, strip, (size_t)keep * rowb, (size_t)U,
-                                      hipMemcpyDeviceToDevice, st));
+            // the session's copy holds both planes of a split tensor, the second one sc->B * slot bytes behind the first
+            for (int pl = 0; pl < (lo ? 2 : 1); ++pl) {
+                char* a = (char*)s.A.p + (size_t)pl * lo * es;
+                char* ctx = (char*)sc->latent_ctx.p + (size_t)pl * sc->B * slot;
+                if (Cs > 0) QTTS_HIP(hipMemcpy2DAsync(a, strip, ctx, slot, (size_t)Cs * rowb, (size_t)U, hipMemcpyDeviceToDevice, st));
+                QTTS_HIP(hipMemcpy2DAsync(ctx, slot, a + (size_t)(Tm - keep) * rowb, strip, (size_t)keep * rowb, (size_t)U, hipMemcpyDeviceToDevice, st));
+            }
         }
     }
     // ================= upsample stages: the current tensor lives in A with Pcur leading rows per strip =================
@@ -466,17 +486,17 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         const long Min = U * S[(size_t)i], Mout = U * S[(size_t)i + 1];
         const int Pn = P[(size_t)i + 1];
         // transposed conv (kernel == stride): A -> R (strips with six leading zero rows for the depthwise conv)
-        gemm(up.ct, (const char*)s.A.p + (size_t)Pcur * s.latP * es, Min, s.latP);
-        zero_pad_rows(s.R.p, S[(size_t)i + 1], Pn, s.latP);
+        gemm(up.ct, (const char*)s.A.p + (size_t)Pcur * s.latP * es, Min, s.latP, lo);
+        zero_pad_rows(s.R.p, S[(size_t)i + 1], Pn, s.latP, true);
         {
             ConvEpi e{};
             e.M = Min; e.N = up.ct.N; e.r = up.ct.r; e.Cout = up.ct.CoutP; e.bias = up.ct.bias.as<float>();
-            e.lens = d_len(i); e.S_in = S[(size_t)i]; e.S_out = S[(size_t)i + 1]; e.P_out = Pn; e.ld_out = s.latP; e.out = s.R.p;
+            e.lens = d_len(i); e.S_in = S[(size_t)i]; e.S_out = S[(size_t)i + 1]; e.P_out = Pn; e.ld_out = s.latP; e.out = s.R.p; e.out_lo = lo;
             epilogue(e);
         }
         // ConvNeXt: depthwise conv + LayerNorm -> A ; pwconv1 + GELU -> Bf ; pwconv2 * gamma + residual -> R (in place)
         launch_dwconv_ln(st, dt, s.R.p, up.dw_w.as<float>(), up.dw_b.as<float>(), up.ln_w.as<float>(), up.ln_b.as<float>(), d_len(i + 1), U,
-                         (int)g.Tmax[(size_t)i + 1], S[(size_t)i + 1], Pn, s.latP, s.A.p);
+                         (int)g.Tmax[(size_t)i + 1], S[(size_t)i + 1], Pn, s.latP, s.A.p, lo);
         gemm(up.pw1, (const char*)s.A.p + (size_t)Pn * s.latP * es, Mout, s.latP);
         {
             ConvEpi e{};
@@ -490,7 +510,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
             ConvEpi e{};
             e.M = Mout; e.N = up.pw2.N; e.r = 1; e.Cout = up.pw2.CoutP; e.bias = up.pw2.bias.as<float>();
             e.scale = up.gamma.as<float>(); e.resid = s.R.p; e.lens = d_len(i + 1); e.S_in = S[(size_t)i + 1]; e.S_out = S[(size_t)i + 1];
-            e.P_out = Pn; e.ld_out = s.latP; e.out = s.R.p;
+            e.P_out = Pn; e.ld_out = s.latP; e.out = s.R.p; e.resid_lo = lo; e.out_lo = lo;
             epilogue(e);
         }
         std::swap(s.A, s.R);  // the stage's result becomes the current tensor
@@ -502,11 +522,12 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
     {
         // decoder.0 (k = 7): A -> snake(block 1 .0) in Bf; the raw result is not needed again
         const long M = U * S[(size_t)nup];
-        gemm(s.dec0, (const char*)s.A.p + (size_t)(Pcur - 6) * s.latP * es, M, s.latP);
+        gemm(s.dec0, (const char*)s.A.p + (size_t)(Pcur - 6) * s.latP * es, M, s.latP, lo);
         ConvEpi e{};
         e.M = M; e.N = s.dec0.N; e.r = 1; e.Cout = CP; e.bias = s.dec0.bias.as<float>();
         e.lens = d_len(nup); e.S_in = S[(size_t)nup]; e.S_out = S[(size_t)nup]; e.P_out = 0; e.ld_out = CP;
         e.out2 = s.Bf.p; e.alpha_exp = s.blocks[0].s0.a.as<float>(); e.beta_den = s.blocks[0].s0.den.as<float>();
+        e.out2_lo = lo;
         epilogue(e);
     }
     // Inside a block R is the residual stream and A the activated input of the next conv, both with maxpad leading
@@ -519,7 +540,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         const long Min = U * S[(size_t)si], Mout = U * S[(size_t)so];
         const int Pn = P[(size_t)so];
         const int CPo = blk.ct.CoutP;
-        gemm(blk.ct, xin, Min, CP);
+        gemm(blk.ct, xin, Min, CP, b < SPLIT_BLOCKS ? lo : 0);
         zero_pad_rows(s.A.p, S[(size_t)so], Pn, CPo);
         {
             ConvEpi e{};
@@ -546,6 +567,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
                 e.alpha_exp = nx.a.as<float>(); e.beta_den = nx.den.as<float>();
                 e.out_f32 = u < 2 ? s.Rf.as<float>() : nullptr;
                 e.out2 = outb->p;
+                e.out2_lo = (u == 2 && b + 1 < SPLIT_BLOCKS) ? lo : 0;
                 Prof pr{};
                 if (profiling) {
                     pr = Prof{nullptr, nullptr, Mout, CPo, un.c1.K + un.c2.K, un.c1.taps + 1, un.c1.dil};
@@ -585,6 +607,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
                 e.alpha_exp = nx.a.as<float>(); e.beta_den = nx.den.as<float>();
                 e.out_f32 = u < 2 ? s.Rf.as<float>() : nullptr;  // after the last unit only the activated copy is read again
                 e.out2 = s.A.p;
+                e.out2_lo = (u == 2 && b + 1 < SPLIT_BLOCKS) ? lo : 0;
                 epilogue(e);
             }
         }
@@ -736,7 +759,7 @@ CodecStream* codec_stream_open(Model& m, int B, int max_chunk) {
     const size_t es = dtype_size(m.dtype);
     const size_t page_elems = (size_t)2 * c.kv_heads * PAGE * c.head_dim;
     sc->kv.alloc((size_t)c.layers * ((size_t)B + 1) * pages * page_elems * es);
-    sc->latent_ctx.alloc((size_t)B * sc->ctx_cap * s.latP * es);
+    sc->latent_ctx.alloc((size_t)B * sc->ctx_cap * s.latP * es * 2);  // room for the remainder plane of bf16 runs
     return sc.release();
 }
 

@@ -72,6 +72,10 @@ __device__ __forceinline__ void conv_epi_resid(const ConvEpi& e, long o_off, flo
         const T* rp = (const T*)e.resid + o_off;
 #pragma unroll
         for (int q = 0; q < 4; ++q) rr[q] = to_f32<T>(rp[q]);
+        if (e.resid_lo) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rr[q] += to_f32<T>(rp[e.resid_lo + q]);
+        }
     } else if (e.resid_f32) {
         ld4(e.resid_f32 + o_off, rr);
     }
@@ -114,24 +118,25 @@ __device__ __forceinline__ void conv_epi_finish(const ConvEpi& e, const EpiCols&
     if (e.out) {
         T* o = (T*)e.out + o_off;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = from_f32<T>(v[q]);
+        for (int q = 0; q < 4; ++q) store_split<T>(o + q, e.out_lo, v[q]);
     }
     if (e.out_f32) *reinterpret_cast<float4*>(e.out_f32 + o_off) = make_float4(v[0], v[1], v[2], v[3]);
     if (e.out2 && e.act2 == 1) {  // ELU of the value the next op would read
         T* o = (T*)e.out2 + o_off;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float x = (e.out_f32 || e.resid_f32) ? v[q] : to_f32<T>(from_f32<T>(v[q]));
-            o[q] = from_f32<T>(x > 0.f ? x : expf(x) - 1.0f);
+            const float x = (e.out_f32 || e.resid_f32 || e.out_lo || e.out2_lo) ? v[q] : to_f32<T>(from_f32<T>(v[q]));
+            store_split<T>(o + q, e.out2_lo, x > 0.f ? x : expf(x) - 1.0f);
         }
     } else if (e.out2) {
         T* o = (T*)e.out2 + o_off;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             // SnakeBeta in f32 on the value the next op would read: the stored (rounded) one unless the stream is kept in f32
-            const float x = (e.out_f32 || e.resid_f32) ? v[q] : to_f32<T>(from_f32<T>(v[q]));
+            // or with its remainder
+            const float x = (e.out_f32 || e.resid_f32 || e.out_lo || e.out2_lo) ? v[q] : to_f32<T>(from_f32<T>(v[q]));
             const float sn = snake_sin<T>(x * c.al[q]);
-            o[q] = from_f32<T>(x + snake_div<T>(sn * sn, c.den[q]));
+            store_split<T>(o + q, e.out2_lo, x + snake_div<T>(sn * sn, c.den[q]));
         }
     }
 }

@@ -71,7 +71,7 @@ struct GenState {
     DevBuf ibuf;                             // int scratch: ids / descriptors
     DevBuf toks_prompt, toks_dec, toks_cp;
     DevBuf row_len, step, eos_step, hist, uniforms, codes, trailing_len;
-    DevBuf trace_logits, trace_hidden;
+    DevBuf trace_logits, trace_hidden, trace_cp;
     StackRun talker, cp;
     size_t cap_rows = 0;
     GemmTimer timer;                         // optional HIP-event timing of every GEMM launch
@@ -97,7 +97,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     const int dt = m.dtype;
     const size_t es = R.es;
     const bool use_graph = dbg ? dbg->use_graph != 0 : true;
-    const bool split = split_activations(dt);
+    const bool split = split_activations(dt), split_cp = split_level(dt) >= 2;
     g.timer.enabled = dbg && dbg->profile_gemm && !use_graph;
     g.timer.used = 0;
     g.timer.bytes = 0;
@@ -232,6 +232,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
                                2 * c.cp.inter, V, Vc, H, Ht, Hc});
     g.ws.x.ensure(rows * Wmax * 4);
     g.ws.alloc_inputs(rows, (size_t)Wmax, (size_t)QD, (size_t)Imax, es, split);
+    R.split(true);  // the runner's copy of the plane offsets follows the allocation
     // up to GEMM_MAX_KS split-K slabs for the small-M kernels (at most 512 rows); the large-M kernel writes one [rows][N] matrix
     g.ws.part.ensure(std::max(rows, (size_t)GEMM_MAX_KS * std::min<size_t>(rows, 512)) * (size_t)Nmax * 4);
     g.ws.q.ensure(rows * QD * 4);
@@ -389,7 +390,8 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     QTTS_HIP(hipEventRecord(ev1, st));
 
     // ------------------------------------------------------------------ frame pieces
-    const bool trace_l = dbg && dbg->logits, trace_h = dbg && dbg->hidden;
+    const bool trace_l = dbg && dbg->logits, trace_h = dbg && dbg->hidden, trace_c = dbg && dbg->cp_logits;
+    if (trace_c) g.trace_cp.ensure((size_t)B * max_new * (G - 1) * Vc * 4);
     if (trace_l) g.trace_logits.ensure((size_t)B * max_new * V * 4);
     if (trace_h) g.trace_hidden.ensure((size_t)B * max_new * H * 4);
     const long row_stride = (long)max_new * G;
@@ -418,8 +420,13 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     };
 
     // logits -> cb0 -> code predictor -> next talker input (generation.rs:1029-1106)
-    auto frame_tail = [&](bool eager_trace) {
-        (void)eager_trace;
+    // host_step: the frame index when the host knows it (eager launches; used by the code-predictor logit trace), -1 under capture
+    auto frame_tail = [&](int host_step) {
+        auto trace_cp = [&](int j) {
+            if (!trace_c || host_step < 0) return;
+            float* dst = g.trace_cp.as<float>() + ((size_t)host_step * (G - 1) + (size_t)j) * Vc;
+            QTTS_HIP(hipMemcpy2DAsync(dst, (size_t)max_new * (G - 1) * Vc * 4, g.ws.part.p, (size_t)Vc * 4, (size_t)Vc * 4, B, hipMemcpyDeviceToDevice, st));
+        };
         R.gemm(m.codec_head, hid_t, B, V, H, 1, H, lo_cp);
         // every sampler also copies the embedding row of the code it drew to where the next pass reads its input
         // (model dtype in front of the H -> Hc projection, f32 when the code predictor is as wide as the talker)
@@ -428,34 +435,40 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         const int in_dt = m.proj ? dt : F32;
         sample(g.ws.part.as<float>(), V, 0, true, m.codec_emb, in0, in_dt);
         // ---- code predictor pass 0: [hidden, embed(cb0)] at positions 0, 1
+        // Five layers deep, the code predictor stays within the bf16 tolerance with single-plane activations (split level 2 splits it too)
+        R.split(split_cp);
+        const long cxn = R.lo_xn;
         const Tok* ct = g.toks_cp.as<Tok>();
         if (m.proj) {
             const int ks = R.ks_for(2 * B, Hc, H);
             R.gemm(m.proj, g.cp_in_t.p, 2 * B, Hc, H, ks, H, lo_cp);
             launch_resid_norm(st, dt, nullptr, g.ws.part.as<float>(), ks, R.kstride(2 * B, Hc), m.proj_b, nullptr, m.cp.layers[0].ln1, c.cp.eps,
-                              g.ws.x.as<float>(), g.ws.xn.p, nullptr, 2 * B, Hc, g.ws.lo_xn);
+                              g.ws.x.as<float>(), g.ws.xn.p, nullptr, 2 * B, Hc, cxn);
         } else {
             launch_resid_norm(st, dt, nullptr, g.cp_in_f.as<float>(), 1, 0, nullptr, nullptr, m.cp.layers[0].ln1, c.cp.eps, g.ws.x.as<float>(),
-                              g.ws.xn.p, nullptr, 2 * B, Hc, g.ws.lo_xn);
+                              g.ws.xn.p, nullptr, 2 * B, Hc, cxn);
         }
-        R.stack(m.cp, 2 * B, ct, g.cp.kv, g.ws.xn.p, nullptr, true, false, g.ws.lo_xn);
-        R.gemm(m.cp_head[0], (char*)g.ws.xn.p + (size_t)B * Hc * es, B, Vc, Hc, 1, Hc, g.ws.lo_xn);
+        R.stack(m.cp, 2 * B, ct, g.cp.kv, g.ws.xn.p, nullptr, true, false, cxn);
+        R.gemm(m.cp_head[0], (char*)g.ws.xn.p + (size_t)B * Hc * es, B, Vc, Hc, 1, Hc, cxn);
+        trace_cp(0);
         sample(g.ws.part.as<float>(), Vc, 1, false, G > 2 ? m.cp_emb[0] : nullptr, inj, in_dt);
         for (int j = 1; j < G - 1; ++j) {  // code_predictor.rs:480-527
             if (m.proj) {
                 const int ks = R.ks_for(B, Hc, H);
                 R.gemm(m.proj, g.ws.act.p, B, Hc, H, ks, H);   // embedding rows: exact in the model dtype, no remainder plane
                 launch_resid_norm(st, dt, nullptr, g.ws.part.as<float>(), ks, R.kstride(B, Hc), m.proj_b, nullptr, m.cp.layers[0].ln1, c.cp.eps,
-                                  g.ws.x.as<float>(), g.ws.xn.p, nullptr, B, Hc, g.ws.lo_xn);
+                                  g.ws.x.as<float>(), g.ws.xn.p, nullptr, B, Hc, cxn);
             } else {
                 launch_resid_norm(st, dt, nullptr, g.ws.q.as<float>(), 1, 0, nullptr, nullptr, m.cp.layers[0].ln1, c.cp.eps, g.ws.x.as<float>(), g.ws.xn.p,
-                                  nullptr, B, Hc, g.ws.lo_xn);
+                                  nullptr, B, Hc, cxn);
             }
-            R.stack(m.cp, B, ct + 2 * B + (size_t)j * B, g.cp.kv, g.ws.xn.p, nullptr, true, true, g.ws.lo_xn);
-            R.gemm(m.cp_head[(size_t)j], g.ws.xn.p, B, Vc, Hc, 1, Hc, g.ws.lo_xn);
+            R.stack(m.cp, B, ct + 2 * B + (size_t)j * B, g.cp.kv, g.ws.xn.p, nullptr, true, true, cxn);
+            R.gemm(m.cp_head[(size_t)j], g.ws.xn.p, B, Vc, Hc, 1, Hc, cxn);
+            trace_cp(j);
             sample(g.ws.part.as<float>(), Vc, j + 1, false, j + 1 < G - 1 ? m.cp_emb[(size_t)j] : nullptr, inj, in_dt);
         }
         // ---- next talker input (talker.rs:461-479 + generation.rs:1096-1106) and its layer-0 norm
+        R.split(true);
         EmbedSumArgs ea{};
         ea.codec_emb = m.codec_emb; ea.cp_emb = (const void* const*)m.cp_emb_ptrs.p; ea.edtype = dt;
         ea.codes_base = g.codes.as<unsigned>(); ea.row_stride = row_stride; ea.step = d_step;
@@ -490,9 +503,9 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
             if (eos[(size_t)b] < 0) return false;
         return true;
     };
-    const bool tracing = trace_l || trace_h;
+    const bool tracing = trace_l || trace_h || trace_c;
     if (tracing) trace_copy(0);
-    frame_tail(false);
+    frame_tail(0);
     steps_done = 1;
     hipGraph_t graph = nullptr;
     if (use_graph && !tracing && max_new > 1) {
@@ -500,7 +513,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         QTTS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
         try {
             talker_step();
-            frame_tail(false);
+            frame_tail(-1);
         } catch (...) {
             hipGraph_t junk = nullptr;
             (void)hipStreamEndCapture(st, &junk);
@@ -534,7 +547,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         } else {
             talker_step();
             if (tracing) trace_copy(steps_done);
-            frame_tail(false);
+            frame_tail(steps_done);
         }
         ++steps_done;
     }
@@ -562,6 +575,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     }
     if (trace_l) QTTS_HIP(hipMemcpy(dbg->logits, g.trace_logits.p, (size_t)B * max_new * V * 4, hipMemcpyDeviceToHost));
     if (trace_h) QTTS_HIP(hipMemcpy(dbg->hidden, g.trace_hidden.p, (size_t)B * max_new * H * 4, hipMemcpyDeviceToHost));
+    if (trace_c) QTTS_HIP(hipMemcpy(dbg->cp_logits, g.trace_cp.p, (size_t)B * max_new * (G - 1) * Vc * 4, hipMemcpyDeviceToHost));
     float ms01 = 0, ms12 = 0;
     QTTS_HIP(hipEventElapsedTime(&ms01, ev0, ev1));
     QTTS_HIP(hipEventElapsedTime(&ms12, ev1, ev2));

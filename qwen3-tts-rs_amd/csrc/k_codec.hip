@@ -16,7 +16,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void rvq_gather_kernel(const float* __restrict__ table, const unsigned* __restrict__ codes,
                                                          const int* __restrict__ rows, const int* __restrict__ starts,
                                                          const int* __restrict__ lens, int Q, int csize, int Dc, int T_max,
-                                                         long S, int P, T* out, int ld) {
+                                                         long S, int P, T* out, int ld, long out_lo) {
     const int u = blockIdx.y, t = blockIdx.x;
     if (t >= lens[u]) return;
     const unsigned* c = codes + ((long)rows[u] * T_max + starts[u] + t) * Q;
@@ -24,16 +24,17 @@ __global__ __launch_bounds__(256) void rvq_gather_kernel(const float* __restrict
     for (int i = threadIdx.x; i < Dc; i += blockDim.x) {
         float s = table[((long)0 * csize + min(c[0], (unsigned)csize - 1)) * Dc + i];
         for (int q = 1; q < Q; ++q) s = s + table[((long)q * csize + min(c[q], (unsigned)csize - 1)) * Dc + i];
-        o[i] = from_f32<T>(s);
+        store_split<T>(o + i, out_lo, s);
     }
 }
 
 void launch_rvq_gather(hipStream_t st, int dtype, const float* table, const unsigned* codes, const int* rows, const int* starts,
-                       const int* lens, int U, int Tc, int Q, int csize, int Dc, int T_max, long S, int P, void* out, int ld) {
+                       const int* lens, int U, int Tc, int Q, int csize, int Dc, int T_max, long S, int P, void* out, int ld, long out_lo) {
     QTTS_CHECK(U >= 1 && Tc >= 1 && Dc <= ld, ERR_SHAPE, "rvq_gather: bad shape");
+    QTTS_CHECK(out_lo == 0 || dtype == BF16, ERR_BAD_ARG, "rvq_gather: a remainder plane exists for bf16 activations only");
     dim3 grid(Tc, U);
-    if (dtype == BF16) hipLaunchKernelGGL(rvq_gather_kernel<bf16_t>, grid, dim3(256), 0, st, table, codes, rows, starts, lens, Q, csize, Dc, T_max, S, P, (bf16_t*)out, ld);
-    else hipLaunchKernelGGL(rvq_gather_kernel<float>, grid, dim3(256), 0, st, table, codes, rows, starts, lens, Q, csize, Dc, T_max, S, P, (float*)out, ld);
+    if (dtype == BF16) hipLaunchKernelGGL(rvq_gather_kernel<bf16_t>, grid, dim3(256), 0, st, table, codes, rows, starts, lens, Q, csize, Dc, T_max, S, P, (bf16_t*)out, ld, out_lo);
+    else hipLaunchKernelGGL(rvq_gather_kernel<float>, grid, dim3(256), 0, st, table, codes, rows, starts, lens, Q, csize, Dc, T_max, S, P, (float*)out, ld, 0L);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -71,7 +72,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void dwconv_ln_kernel(const T* __restrict__ x, const float* __restrict__ w /*[C][7]*/,
                                                         const float* __restrict__ b, const float* __restrict__ ln_w,
                                                         const float* __restrict__ ln_b, const int* __restrict__ lens,
-                                                        long S, int P, int C, T* out) {
+                                                        long S, int P, int C, T* out, long x_lo) {
     __shared__ float red[32];
     extern __shared__ float ybuf[];
     const int u = blockIdx.y, t = blockIdx.x;
@@ -81,7 +82,11 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const T* __restrict__ x,
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float acc = b[c];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) acc += w[c * 7 + k] * to_f32<T>(x[(row + k - 6) * C + c]);
+        for (int k = 0; k < 7; ++k) {
+            float xv = to_f32<T>(x[(row + k - 6) * C + c]);
+            if (x_lo) xv += to_f32<T>(x[x_lo + (row + k - 6) * C + c]);
+            acc += w[c * 7 + k] * xv;
+        }
         ybuf[c] = acc;
         sum += acc;
     }
@@ -97,11 +102,12 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const T* __restrict__ x,
 }
 
 void launch_dwconv_ln(hipStream_t st, int dtype, const void* x, const float* w, const float* b, const float* ln_w, const float* ln_b,
-                      const int* lens, int U, int Tmax, long S, int P, int C, void* out) {
+                      const int* lens, int U, int Tmax, long S, int P, int C, void* out, long x_lo) {
     QTTS_CHECK(P >= 6 && C >= 1 && C * 4 <= 64 * 1024, ERR_SHAPE, "dwconv_ln: needs 6 padding rows and C <= 16384");
+    QTTS_CHECK(x_lo == 0 || dtype == BF16, ERR_BAD_ARG, "dwconv_ln: a remainder plane exists for bf16 activations only");
     dim3 grid(Tmax, U);
-    if (dtype == BF16) hipLaunchKernelGGL(dwconv_ln_kernel<bf16_t>, grid, dim3(256), (size_t)C * 4, st, (const bf16_t*)x, w, b, ln_w, ln_b, lens, S, P, C, (bf16_t*)out);
-    else hipLaunchKernelGGL(dwconv_ln_kernel<float>, grid, dim3(256), (size_t)C * 4, st, (const float*)x, w, b, ln_w, ln_b, lens, S, P, C, (float*)out);
+    if (dtype == BF16) hipLaunchKernelGGL(dwconv_ln_kernel<bf16_t>, grid, dim3(256), (size_t)C * 4, st, (const bf16_t*)x, w, b, ln_w, ln_b, lens, S, P, C, (bf16_t*)out, x_lo);
+    else hipLaunchKernelGGL(dwconv_ln_kernel<float>, grid, dim3(256), (size_t)C * 4, st, (const float*)x, w, b, ln_w, ln_b, lens, S, P, C, (float*)out, 0L);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -23,7 +23,7 @@ namespace qtts {
 // Tuning switches, read from the environment once per process (the first call from any thread fixes them for all).
 struct GemmEnv {
     int force_kind, force_nt, force_nch, min_blocks;
-    bool xcd_order, conv_halo_off;
+    bool xcd_order, conv_halo_off, lo_half_rows;
 };
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
@@ -31,7 +31,8 @@ static int env_int(const char* name, int dflt) {
 }
 static const GemmEnv& gemm_env() {
     static const GemmEnv e{env_int("QTTS_GEMM_KIND", -1), env_int("QTTS_GEMM_NT", 0), env_int("QTTS_GEMM_NCH", 0),
-                           env_int("QTTS_GEMM_MIN_BLOCKS", 192), env_int("QTTS_GEMM_XCD", 1) != 0, env_int("QTTS_CONV_HALO", 1) == 0};
+                           env_int("QTTS_GEMM_MIN_BLOCKS", 192), env_int("QTTS_GEMM_XCD", 1) != 0, env_int("QTTS_CONV_HALO", 1) == 0,
+                           env_int("QTTS_GEMM_LO_HALF", 1) != 0};
     return e;
 }
 
@@ -200,26 +201,28 @@ __global__ __launch_bounds__(256) void gemm_ldsx_kernel(const T* __restrict__ W,
     const int row0 = bz * (16 * MT);
     const size_t kbeg = (size_t)ks * NCH * F::CHUNK;
 
-    // X fragment blocks -> LDS (asynchronous, no VGPRs); the lo plane's blocks follow the hi plane's
-    for (int fb = wave; fb < (LO ? 2 : 1) * NFB; fb += 4) {
-        const int pl = fb / NFB, f = fb % NFB;
-        const int c = f / (MT * 2), i = (f >> 1) % MT, h = f & 1;
-        const T* src = X + (pl ? x_lo : 0) + (size_t)(row0 + 16 * i + r) * ldx + kbeg + (size_t)c * F::CHUNK + g * F::EPL + h * HALF;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(xs + fb * 64), 16, 0, 0);
-    }
+    // X fragment blocks -> LDS (asynchronous, no VGPRs); a remainder plane's blocks follow the first plane's in LDS
+    auto dma_plane = [&](int pl) {
+        for (int f = wave; f < NFB; f += 4) {
+            const int c = f / (MT * 2), i = (f >> 1) % MT, h = f & 1;
+            const T* src = X + (pl ? x_lo : 0) + (size_t)(row0 + 16 * i + r) * ldx + kbeg + (size_t)c * F::CHUNK + g * F::EPL + h * HALF;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(xs + (pl * NFB + f) * 64), 16, 0, 0);
+        }
+    };
+    dma_plane(0);
     // all W loads of this block's K range
     F a[NCH][NT];
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-        {
+        for (int j = 0; j < NT; ++j) {
             // one row slice: every weight byte is read by exactly one block (streamed); several: the slices share it through L2
             const T* wsrc = W + (size_t)(n0 + 16 * j + r) * K + kbeg + (size_t)c * F::CHUNK + g * F::EPL;
             if (Z > 1) a[c][j].load(wsrc);
             else a[c][j].load_stream(wsrc);
         }
+    if constexpr (LO) dma_plane(1);
 
     f32x4_t acc[MT][NT];
 #pragma unroll
@@ -232,18 +235,13 @@ __global__ __launch_bounds__(256) void gemm_ldsx_kernel(const T* __restrict__ W,
     for (int c = 0; c < NCH; ++c) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            F b;
-            const uint4 h0 = xs[((c * MT + i) * 2 + 0) * 64 + lane];
-            const uint4 h1 = xs[((c * MT + i) * 2 + 1) * 64 + lane];
-            __builtin_memcpy(&b, &h0, 16);
-            __builtin_memcpy((char*)&b + 16, &h1, 16);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[c][j], b, acc[i][j]);
-            if constexpr (LO) {
-                const uint4 l0 = xs[(NFB + (c * MT + i) * 2 + 0) * 64 + lane];
-                const uint4 l1 = xs[(NFB + (c * MT + i) * 2 + 1) * 64 + lane];
-                __builtin_memcpy(&b, &l0, 16);
-                __builtin_memcpy((char*)&b + 16, &l1, 16);
+            for (int pl = 0; pl < (LO ? 2 : 1); ++pl) {
+                F b;
+                const uint4 h0 = xs[(pl * NFB + (c * MT + i) * 2 + 0) * 64 + lane];
+                const uint4 h1 = xs[(pl * NFB + (c * MT + i) * 2 + 1) * 64 + lane];
+                __builtin_memcpy(&b, &h0, 16);
+                __builtin_memcpy((char*)&b + 16, &h1, 16);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[c][j], b, acc[i][j]);
             }
@@ -435,7 +433,7 @@ void launch_gemm_rows(hipStream_t st, int dtype, const void* W, const void* X, f
 
 // Same GEMM with the conv epilogue applied in registers (no f32 output): e.acc is ignored, e.M bounds the rows.
 void launch_gemm_rows_epi(hipStream_t st, int dtype, const void* W, const void* X, int K, int ldx, int taps, long tap_stride,
-                          const ConvEpi& e) {
+                          const ConvEpi& e, long x_lo) {
     const long M = e.M;
     const int N = e.N;
     QTTS_CHECK(M >= 1 && N % 64 == 0 && taps >= 1 && K % taps == 0, ERR_SHAPE, "gemm_rows: N must be a multiple of 64");
@@ -444,10 +442,12 @@ void launch_gemm_rows_epi(hipStream_t st, int dtype, const void* W, const void* 
     QTTS_CHECK(e.out2 == nullptr || e.act2 == 1 || (e.alpha_exp && e.beta_den), ERR_BAD_ARG, "gemm_rows: snake output without parameters");
     const int chunk = dtype == BF16 ? 64 : 32;
     QTTS_CHECK((K / taps) % chunk == 0, ERR_SHAPE, "gemm_rows: channels per tap must be a multiple of the K chunk");
-    if (!gemm_env().conv_halo_off && launch_conv_halo(st, dtype, W, X, K, ldx, taps, tap_stride, e)) return;
+    QTTS_CHECK(x_lo == 0 || dtype == BF16, ERR_BAD_ARG, "gemm_rows: a remainder plane exists for bf16 activations only");
+    if (x_lo == 0 && !gemm_env().conv_halo_off && launch_conv_halo(st, dtype, W, X, K, ldx, taps, tap_stride, e)) return;
     const long Mpad = (M + 63) / 64 * 64;
     const int cpt = K / taps / chunk;
-    if (dtype == BF16) launch_rows_t<bf16_t, true>(st, (const bf16_t*)W, (const bf16_t*)X, nullptr, Mpad, N, K, ldx, cpt, tap_stride, e);
+    if (dtype == BF16 && x_lo) launch_rows_t<bf16_t, true, true>(st, (const bf16_t*)W, (const bf16_t*)X, nullptr, Mpad, N, K, ldx, cpt, tap_stride, e, x_lo);
+    else if (dtype == BF16) launch_rows_t<bf16_t, true>(st, (const bf16_t*)W, (const bf16_t*)X, nullptr, Mpad, N, K, ldx, cpt, tap_stride, e);
     else launch_rows_t<float, true>(st, (const float*)W, (const float*)X, nullptr, Mpad, N, K, ldx, cpt, tap_stride, e);
 }
 
@@ -500,7 +500,11 @@ template <typename T, bool LO>
 static void launch_plan(hipStream_t st, const GemmPlan& p, const T* W, const T* X, float* out, int Mpad, int N, int K, int ldx, long x_lo) {
     if (p.kind == 1) {
         bool ok = false;
-        if (Mpad == 32) ok = launch_ldsx_mt<T, 2, LO>(st, W, X, out, Mpad, N, K, ldx, p.NT, p.NCH, x_lo);
+        // with a remainder plane the X tile of 64 rows x 8 chunks fills 128 KB of LDS (one block per CU): 32-row slices
+        // halve it, and the two slices of a weight tile share it through their XCD's L2
+        // (worth it where one 64-row block per CU would need a second round: more than 256 blocks)
+        const bool half_rows = LO && p.NCH >= 8 && Mpad == 64 && (long)(N / (64 * p.NT)) * p.KS > 256 && gemm_env().lo_half_rows;
+        if (Mpad == 32 || half_rows) ok = launch_ldsx_mt<T, 2, LO>(st, W, X, out, Mpad, N, K, ldx, p.NT, p.NCH, x_lo);
         else ok = launch_ldsx_mt<T, 4, LO>(st, W, X, out, Mpad, N, K, ldx, p.NT, p.NCH, x_lo);
         QTTS_CHECK(ok, ERR_STATE, "gemm: no kernel instance for the planned variant");
         return;

@@ -167,11 +167,14 @@ struct ConvEpi {
     void* out2;              // optional SnakeBeta(out)
     const float* alpha_exp;  // exp(alpha)
     const float* beta_den;   // exp(beta) + 1e-9
+    // bf16 runs: element offsets of the remainder planes of resid / out / out2 (see launch_gemm), 0 = single plane
+    long resid_lo, out_lo, out2_lo;
 };
 void launch_conv_epilogue(hipStream_t st, int dtype, const ConvEpi& e);
 // GEMM + epilogue in one launch (k_gemm.hip): rows e.M, columns e.N; e.acc is not used
+// x_lo != 0: X carries a remainder plane (tap-addressed kernel only)
 void launch_gemm_rows_epi(hipStream_t st, int dtype, const void* W, const void* X, int K, int ldx, int taps, long tap_stride,
-                          const ConvEpi& e);
+                          const ConvEpi& e, long x_lo = 0);
 // k_conv.hip: same contract with the input tile held in LDS; false = shape not covered (use launch_gemm_rows_epi).
 // X must be readable for CONV_HALO_SLACK rows past e.M.
 constexpr long CONV_HALO_SLACK = 384;
@@ -180,9 +183,9 @@ bool conv_unit_supported(int dtype, int C, int taps, int dil);
 bool launch_conv_unit(hipStream_t st, int dtype, const void* W1, const void* W2, const void* X, int C, int taps, int dil, const float* bias1,
                       const float* alpha2, const float* den2, const ConvEpi& e);
 void launch_rvq_gather(hipStream_t st, int dtype, const float* table, const unsigned* codes, const int* rows, const int* starts,
-                       const int* lens, int U, int Tc, int Q, int csize, int Dc, int T_max, long S, int P, void* out, int ld);
+                       const int* lens, int U, int Tc, int Q, int csize, int Dc, int T_max, long S, int P, void* out, int ld, long out_lo = 0);
 void launch_dwconv_ln(hipStream_t st, int dtype, const void* x, const float* w, const float* b, const float* ln_w, const float* ln_b,
-                      const int* lens, int U, int Tmax, long S, int P, int C, void* out);
+                      const int* lens, int U, int Tmax, long S, int P, int C, void* out, long x_lo = 0);
 void launch_final_conv(hipStream_t st, int dtype, const void* x, const float* w, float bias, const int* nvalid, int U, long Tmax, long S,
                        int P, int C, float* wav, long wav_stride);
 

@@ -27,12 +27,14 @@ struct Workspace {
     }
 };
 
-// Activations of bf16 runs are split into a bf16 value and a bf16 remainder unless QTTS_SPLIT_ACT=0 (single plane: one MFMA
-// pass fewer per GEMM, logits then carry bf16 rounding noise of about 2e-2 max-abs at the 28-layer shapes).
-inline bool split_activations(int dtype) {
-    static const bool on = !(getenv("QTTS_SPLIT_ACT") && atoi(getenv("QTTS_SPLIT_ACT")) == 0);
-    return dtype == BF16 && on;
+// Activations of bf16 runs are split into a bf16 value and a bf16 remainder.  QTTS_SPLIT_ACT: 0 = never (one MFMA pass
+// fewer per GEMM; logits then carry bf16 rounding noise of about 2e-2 max-abs at the 28-layer shapes), 1 (default) = the
+// talker and the codec's low-rate stages, 2 = the five-layer code predictor too.
+inline int split_level(int dtype) {
+    static const int level = getenv("QTTS_SPLIT_ACT") ? atoi(getenv("QTTS_SPLIT_ACT")) : 1;
+    return dtype == BF16 ? level : 0;
 }
+inline bool split_activations(int dtype) { return split_level(dtype) >= 1; }
 
 struct GemmTimer {
     bool enabled = false;
@@ -76,13 +78,23 @@ struct Runner {
     hipStream_t st;
     int dt;
     size_t es;
+    // remainder-plane offsets the layers use for xn / attn / act: the workspace's, or 0 after split(false) (a stack whose
+    // depth keeps bf16 rounding within the tolerance runs single-plane: one MFMA pass and one X tile fewer per GEMM)
+    long lo_xn, lo_attn, lo_act;
+    void split(bool on) {
+        lo_xn = on ? g.lo_xn : 0;
+        lo_attn = on ? g.lo_attn : 0;
+        lo_act = on ? g.lo_act : 0;
+    }
     // from this many tokens on the large-M kernel (no split-K slabs) is used; the slab workspaces are sized for at most 512 rows
     static int rows_kernel_min_m() {
         static const int v = getenv("QTTS_ROWS_MIN_M") ? std::min(513, std::max(17, atoi(getenv("QTTS_ROWS_MIN_M")))) : 513;
         return v;
     }
 
-    Runner(Model& model, Workspace& ws, GemmTimer* t) : m(model), g(ws), timer(t), st(model.ctx->stream), dt(model.dtype), es(dtype_size(model.dtype)) {}
+    Runner(Model& model, Workspace& ws, GemmTimer* t) : m(model), g(ws), timer(t), st(model.ctx->stream), dt(model.dtype), es(dtype_size(model.dtype)) {
+        split(true);
+    }
 
     // split-K factor the consumers of g.part must assume for a GEMM of this shape
     int ks_for(int M, int N, int K) const {
@@ -118,34 +130,34 @@ struct Runner {
     // On entry x holds the residual stream and xn = RMSNorm_ln1(x); on exit xn = RMSNorm_next(x) with `next_norm`
     // the following layer's input norm (or the stack's final norm).
     // `decode`: every token's key range ends at its own position and tokens of the launch do not attend to each other
-    // xn_out_lo: remainder-plane offset of xn_out (g.lo_xn when xn_out is g.xn)
+    // xn_out_lo: remainder-plane offset of xn_out (lo_xn when xn_out is g.xn)
     void layer(const StackW& s, int l, int M, const Tok* toks, const KVView& kv, int kv_layer, const float* next_norm, void* xn_out,
                float* xn_f32_out, bool decode, long xn_out_lo) {
         const StackCfg& c = s.cfg;
         const LayerW& w = s.layers[(size_t)l];
         const int nq = c.nh * c.d, nqkv = (c.nh + 2 * c.nkv) * c.d;
         int ks = ks_for(M, nqkv, c.hidden);
-        gemm(w.qkv, g.xn.p, M, nqkv, c.hidden, ks, c.hidden, g.lo_xn);
+        gemm(w.qkv, g.xn.p, M, nqkv, c.hidden, ks, c.hidden, lo_xn);
         QkvPostArgs qa{};
         qa.part = g.part.as<float>(); qa.KS = ks; qa.ks_stride = kstride(M, nqkv); qa.bias = w.qkv_bias;
         qa.q_norm = w.q_norm; qa.k_norm = w.k_norm; qa.eps = c.eps; qa.cos = s.cos.as<float>(); qa.sin = s.sin.as<float>();
         qa.rope_mode = 0; qa.toks = toks; qa.M = M; qa.nh = c.nh; qa.nkv = c.nkv; qa.d = c.d; qa.layer = kv_layer;
         qa.q_out = g.q.as<float>();
         if (decode) {
-            launch_attention_decode(st, dt, qa, kv, (float)std::pow((double)c.d, -0.5), g.attn.p, g.lo_attn);
+            launch_attention_decode(st, dt, qa, kv, (float)std::pow((double)c.d, -0.5), g.attn.p, lo_attn);
         } else {
             launch_qkv_post(st, dt, qa, kv);
-            launch_attention(st, dt, g.q.as<float>(), toks, kv, kv_layer, M, c.nh, (float)std::pow((double)c.d, -0.5), g.attn.p, g.lo_attn);
+            launch_attention(st, dt, g.q.as<float>(), toks, kv, kv_layer, M, c.nh, (float)std::pow((double)c.d, -0.5), g.attn.p, lo_attn);
         }
         ks = ks_for(M, c.hidden, nq);
-        gemm(w.o, g.attn.p, M, c.hidden, nq, ks, nq, g.lo_attn);
+        gemm(w.o, g.attn.p, M, c.hidden, nq, ks, nq, lo_attn);
         launch_resid_norm(st, dt, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), w.o_bias, w.ls_attn, w.ln2, c.eps,
-                          g.x.as<float>(), g.xn.p, nullptr, M, c.hidden, g.lo_xn);
+                          g.x.as<float>(), g.xn.p, nullptr, M, c.hidden, lo_xn);
         ks = ks_for(M, 2 * c.inter, c.hidden);
-        gemm(w.gate_up, g.xn.p, M, 2 * c.inter, c.hidden, ks, c.hidden, g.lo_xn);
-        launch_swiglu(st, dt, g.part.as<float>(), ks, kstride(M, 2 * c.inter), g.act.p, M, c.inter, g.lo_act);
+        gemm(w.gate_up, g.xn.p, M, 2 * c.inter, c.hidden, ks, c.hidden, lo_xn);
+        launch_swiglu(st, dt, g.part.as<float>(), ks, kstride(M, 2 * c.inter), g.act.p, M, c.inter, lo_act);
         ks = ks_for(M, c.hidden, c.inter);
-        gemm(w.down, g.act.p, M, c.hidden, c.inter, ks, c.inter, g.lo_act);
+        gemm(w.down, g.act.p, M, c.hidden, c.inter, ks, c.inter, lo_act);
         launch_resid_norm(st, dt, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), nullptr, w.ls_mlp, next_norm, c.eps,
                           g.x.as<float>(), xn_out, xn_f32_out, M, c.hidden, xn_out_lo);
     }
@@ -157,7 +169,7 @@ struct Runner {
         for (int l = 0; l < s.cfg.layers; ++l) {
             const bool last = l + 1 == s.cfg.layers;
             layer(s, l, M, toks, kv, kv_per_layer ? l : 0, last ? s.final_norm : s.layers[(size_t)l + 1].ln1, last ? final_xn : g.xn.p,
-                  last ? final_xn_f32 : nullptr, decode, last ? final_xn_lo : g.lo_xn);
+                  last ? final_xn_f32 : nullptr, decode, last ? final_xn_lo : lo_xn);
         }
     }
 };

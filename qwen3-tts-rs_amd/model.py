@@ -296,12 +296,15 @@ class Model:
             outs[i].codes = codes[i].ctypes.data_as(C.POINTER(C.c_uint32))
         sc = sampling.to_c()
         dbg = _lib.GenDebug()
-        logits = hidden = None
+        logits = hidden = cp_logits = None
         if trace:
+            Vc = self.config["talker_config"]["code_predictor_config"]["vocab_size"]
             logits = np.zeros((n, max_new_tokens, V), np.float32)
             hidden = np.zeros((n, max_new_tokens, H), np.float32)
+            cp_logits = np.zeros((n, max_new_tokens, G - 1, Vc), np.float32)
             dbg.logits = logits.ctypes.data_as(C.POINTER(C.c_float))
             dbg.hidden = hidden.ctypes.data_as(C.POINTER(C.c_float))
+            dbg.cp_logits = cp_logits.ctypes.data_as(C.POINTER(C.c_float))
         dbg.use_graph = int(use_graph)
         dbg.profile_gemm = int(profile_gemm)
         dbg.min_new_tokens = int(min_new_tokens)
@@ -328,6 +331,7 @@ class Model:
         if trace:
             out.logits = logits[:, :steps]
             out.hidden = hidden[:, :steps]
+            out.cp_logits = cp_logits[:, :steps]
         return out
 
     def gemm_profile(self):

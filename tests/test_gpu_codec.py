@@ -8,7 +8,7 @@ from conftest import make_oracle, snr_db
 pytestmark = pytest.mark.gpu
 
 SNR_F32_DB = 40.0      # north-star bar
-SNR_BF16_DB = 28.0     # bf16 GEMM inputs / activation storage against an f32 oracle on identical bf16-rounded weights
+SNR_BF16_DB = 40.0     # the same bar: bf16 runs carry a remainder plane behind the activations that limit it
 
 
 @pytest.fixture(scope="module")
@@ -81,7 +81,7 @@ def test_bf16_decode(bind, golden):
         m.close()
 
 
-@pytest.mark.parametrize("dtype,causal_db", [("bf16", 28.0), ("f32", 80.0)])
+@pytest.mark.parametrize("dtype,causal_db", [("bf16", 36.0), ("f32", 80.0)])
 def test_full_size_codec_properties(dtype, causal_db):
     """Reference-default codec shapes (1024-wide transformer, 1536-channel vocoder, x1920 upsampling), sizes the
     oracle cannot decode in seconds: causality (a prefix decodes to a prefix; in bf16 only down to the rounding

@@ -80,6 +80,6 @@ def test_stream_at_the_real_codec_shape_bf16():
         for b in range(2):
             # a push and the whole decode pick different GEMM tilings (summation order), and every activation is stored in
             # bf16: two bf16 runs agree to the bf16 noise floor (~33 dB against f32), the f32 test above is the exact one
-            assert snr_db(whole[b], wav[b]) > 28.0, b
+            assert snr_db(whole[b], wav[b]) > 36.0, b
     finally:
         m.close()

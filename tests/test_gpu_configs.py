@@ -103,7 +103,7 @@ def test_long_form_codec_decode():
         ref = wavs[0][1920 * 256 - 555:][:1920 * 256 - 555]
         n = min(len(ref), len(part) - 32 * 1920)
         from conftest import snr_db
-        assert snr_db(part[32 * 1920:32 * 1920 + n], ref[:n]) > 28.0
+        assert snr_db(part[32 * 1920:32 * 1920 + n], ref[:n]) > 36.0
     finally:
         m.close()
 
@@ -163,6 +163,6 @@ def test_headline_configuration_at_full_size():
             head = s.push(a.codes[:, :25, :Q])
         assert head.shape == (B, 1920 * 25 - 555)
         for u in (0, 31, 63):
-            assert snr_db(wavs[u][:head.shape[1]], head[u]) > 28.0, u
+            assert snr_db(wavs[u][:head.shape[1]], head[u]) > 36.0, u
     finally:
         m.close()
