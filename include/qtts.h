@@ -183,6 +183,15 @@ int qtts_encode_audio(qtts_model* m, const float* audio, const int* n_samples, i
  * (model/mod.rs:520-528): audio [B][max_samples] f32 @ 24 kHz -> mel_out [B][frames_stride][128]. */
 int qtts_mel(qtts_model* m, const float* audio, const int* n_samples, int B, int max_samples, float* mel_out,
              int frames_stride, int* n_frames);
+/* qtts_mel for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  No counterpart in the reference.  Same arguments and results as qtts_mel, but the device-side staging
+ * of the clips, their lengths and the result lives in one fixed array per GPU (qtts_mel_noalloc_capacity() bytes, 16 MiB)
+ * instead of buffers grown on demand: the call issues no hipMalloc / hipFree.  It fails with QTTS_ERR_SHAPE when
+ * pad256(4 B) + pad256(4 B max_samples) + 512 B frames_stride exceeds that capacity.  Calls on one GPU share the array:
+ * they must not overlap in time. */
+int qtts_mel_noalloc(qtts_model* m, const float* audio, const int* n_samples, int B, int max_samples, float* mel_out,
+                     int frames_stride, int* n_frames);
+int64_t qtts_mel_noalloc_capacity(void);
 /* ConditionalGeneration::encode_speaker (nn/generation.rs:140) on top of qtts_mel: emb_out [B][enc_dim]. */
 int qtts_speaker_embed(qtts_model* m, const float* audio, const int* n_samples, int B, int max_samples, float* emb_out);
 /* The same on a mel the caller already holds - Model::create_voice_clone_prompt_from_mel (model/mod.rs:579-612):

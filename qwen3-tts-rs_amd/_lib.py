@@ -51,7 +51,8 @@ EXPORTS = ["qtts_init", "qtts_shutdown", "qtts_last_error", "qtts_stream", "qtts
            "qtts_model_load_tensor_device", "qtts_model_finalize", "qtts_model_free", "qtts_generate", "qtts_generate_ex",
            "qtts_last_timing", "qtts_codec_decode", "qtts_mel", "qtts_speaker_embed", "qtts_model_info",
            "qtts_gemm_profile", "qtts_bench_gemm", "qtts_bench_stream", "qtts_encode_audio",
-           "qtts_speaker_embed_mel", "qtts_codec_stream_open", "qtts_codec_stream_push", "qtts_codec_stream_close"]
+           "qtts_speaker_embed_mel", "qtts_codec_stream_open", "qtts_codec_stream_push", "qtts_codec_stream_close",
+           "qtts_mel_noalloc", "qtts_mel_noalloc_capacity"]
 
 _lib = None
 
@@ -82,6 +83,9 @@ def load():
     lib.qtts_codec_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_int64, C.c_void_p]
     lib.qtts_mel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    lib.qtts_mel_noalloc.argtypes = lib.qtts_mel.argtypes
+    lib.qtts_mel_noalloc_capacity.restype = C.c_int64
+    lib.qtts_mel_noalloc_capacity.argtypes = []
     lib.qtts_speaker_embed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.qtts_speaker_embed_mel.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.qtts_encode_audio.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]

@@ -62,6 +62,7 @@ int qtts_init(int device_ordinal, qtts_ctx** out) {
     std::unique_ptr<qtts_ctx> c(new qtts_ctx());
     c->c.device = device_ordinal;
     QTTS_HIP(hipStreamCreateWithFlags(&c->c.stream, hipStreamNonBlocking));
+    (void)mel_scratch(device_ordinal);  // device address of this GPU's fixed staging array (qtts_mel_noalloc)
     *out = c.release();
     QTTS_API_END
 }
@@ -185,6 +186,16 @@ int qtts_mel(qtts_model* m, const float* audio, const int* n_samples, int B, int
     run_mel(m->m, audio, n_samples, B, max_samples, mel_out, frames_stride, n_frames);
     QTTS_API_END
 }
+
+int qtts_mel_noalloc(qtts_model* m, const float* audio, const int* n_samples, int B, int max_samples, float* mel_out, int frames_stride,
+                     int* n_frames) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(m && audio && n_samples && mel_out && n_frames, ERR_BAD_ARG, "qtts_mel_noalloc: null argument");
+    run_mel_noalloc(m->m, audio, n_samples, B, max_samples, mel_out, frames_stride, n_frames);
+    QTTS_API_END
+}
+
+int64_t qtts_mel_noalloc_capacity(void) { return (int64_t)mel_scratch_bytes(); }
 
 int qtts_speaker_embed(qtts_model* m, const float* audio, const int* n_samples, int B, int max_samples, float* emb_out) {
     QTTS_API_BEGIN

@@ -24,6 +24,12 @@ void run_encode_audio(Model& m, const float* audio, const int* n_samples, int B,
 void finalize_speaker(Model& m);
 void run_mel(Model& m, const float* audio, const int* n_samples, int B, int max_samples, float* mel_out, int frames_stride,
              int* n_frames);
+// the same without any allocation: staging in a fixed per-GPU device array (speaker.cpp); mel_scratch looks the array's
+// device address up once per GPU and must be called with that GPU current
+void run_mel_noalloc(Model& m, const float* audio, const int* n_samples, int B, int max_samples, float* mel_out, int frames_stride,
+                     int* n_frames);
+unsigned char* mel_scratch(int device);
+size_t mel_scratch_bytes();
 void run_speaker_embed(Model& m, const float* audio, const int* n_samples, int B, int max_samples, float* emb_out);
 void run_speaker_embed_mel(Model& m, const float* mel, const int* n_frames, int B, int frames_stride, float* emb_out);
 

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 
 #include "generate.hpp"
 #include "prep.hpp"
@@ -209,6 +210,68 @@ void run_mel(Model& m, const float* audio, const int* n_samples, int B, int max_
     QTTS_HIP(hipMemcpyAsync(mel_out, s.mel_f32.p, (size_t)B * frames_stride * NMEL * 4, hipMemcpyDeviceToHost, st));
     QTTS_HIP(hipStreamSynchronize(st));
     for (int u = 0; u < B; ++u) n_frames[u] = b.frames[(size_t)u];
+}
+
+// ------------------------------------------------------------------------------------------------
+// run_mel for callers that must not allocate: the staging copies of the clips, of their lengths and of the result live in
+// one fixed device array per GPU instead of buffers grown on demand.  Every call on a GPU shares that GPU's array (calls that
+// overlap on one GPU race); a call overwrites what it reads back, so nothing has to be cleared between calls except
+// the result region, which the call itself zeroes.
+constexpr size_t MEL_SCRATCH_BYTES = (size_t)16 << 20;
+static __device__ __align__(256) unsigned char scratch[MEL_SCRATCH_BYTES];
+namespace {
+constexpr int MAX_DEVICES = 64;
+unsigned char* g_scratch_ptr[MAX_DEVICES] = {};  // device address of `scratch` on each GPU (the array's name is only a host-side handle)
+std::mutex g_scratch_mu;
+size_t pad256(size_t n) { return (n + 255) / 256 * 256; }
+}  // namespace
+
+// Looks up this GPU's copy of the array once; called with `device` current (qtts_init, and again by the entry point in case
+// the context was created by other means).
+unsigned char* mel_scratch(int device) {
+    QTTS_CHECK(device >= 0 && device < MAX_DEVICES, ERR_BAD_ARG, "mel scratch: device ordinal out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        QTTS_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        QTTS_CHECK(p != nullptr, ERR_HIP, "mel scratch: no device address for the scratch array");
+        g_scratch_ptr[device] = (unsigned char*)p;
+    }
+    return g_scratch_ptr[device];
+}
+
+size_t mel_scratch_bytes() { return MEL_SCRATCH_BYTES; }
+
+void run_mel_noalloc(Model& m, const float* audio, const int* n_samples, int B, int max_samples, float* mel_out, int frames_stride, int* n_frames) {
+    QTTS_CHECK(m.finalized && m.spk_state, ERR_STATE, "model is not finalized");
+    QTTS_CHECK(B >= 1 && max_samples >= 1 && frames_stride >= 1, ERR_BAD_ARG, "mel: bad batch shape");
+    QTTS_HIP(hipSetDevice(m.ctx->device));
+    SpeakerState& s = *m.spk_state;
+    hipStream_t st = m.ctx->stream;
+    int max_frames = 0;
+    for (int u = 0; u < B; ++u) {
+        QTTS_CHECK(n_samples[u] > MELPAD && n_samples[u] <= max_samples, ERR_BAD_ARG,
+                   "mel: every clip needs more than 384 samples (reflect padding) and at most max_samples");
+        n_frames[u] = (n_samples[u] + 2 * MELPAD - NFFT) / HOP + 1;
+        QTTS_CHECK(n_frames[u] >= 1, ERR_BAD_ARG, "mel: audio shorter than one STFT frame");
+        max_frames = std::max(max_frames, n_frames[u]);
+    }
+    QTTS_CHECK(frames_stride >= max_frames, ERR_SHAPE, "mel: frames_stride too small");
+    const size_t b_len = pad256((size_t)B * 4), b_audio = pad256((size_t)B * max_samples * 4), b_mel = (size_t)B * frames_stride * NMEL * 4;
+    QTTS_CHECK(b_len + b_audio + b_mel <= MEL_SCRATCH_BYTES, ERR_SHAPE,
+               "mel (no-allocation entry point): clips + result need " + std::to_string(b_len + b_audio + b_mel) +
+                   " bytes of staging, the fixed scratch array holds " + std::to_string(MEL_SCRATCH_BYTES) + "; use qtts_mel or a smaller batch");
+    unsigned char* base = mel_scratch(m.ctx->device);
+    int* d_len = (int*)base;
+    float* d_audio = (float*)(base + b_len);
+    float* d_mel = (float*)(base + b_len + b_audio);
+    QTTS_HIP(hipMemcpyAsync(d_len, n_samples, (size_t)B * 4, hipMemcpyHostToDevice, st));
+    QTTS_HIP(hipMemcpyAsync(d_audio, audio, (size_t)B * max_samples * 4, hipMemcpyHostToDevice, st));
+    QTTS_HIP(hipMemsetAsync(d_mel, 0, b_mel, st));
+    launch_mel(st, F32, d_audio, d_len, B, max_samples, max_frames, s.window.as<float>(), s.twiddle.as<float>(), s.fbT.as<float>(), d_mel,
+               frames_stride, nullptr, 0, 0);
+    QTTS_HIP(hipMemcpyAsync(mel_out, d_mel, b_mel, hipMemcpyDeviceToHost, st));
+    QTTS_HIP(hipStreamSynchronize(st));
 }
 
 namespace {

@@ -405,8 +405,9 @@ class Model:
             raise QttsError(-5, "ICL mode requires ref_text to be present")
         return VoiceClonePromptItem.icl(self.encode_audio([audio])[0], emb, ref_text_ids)
 
-    def compute_mel_spectrogram(self, audio: Sequence[np.ndarray]):
-        """Model::compute_mel_spectrogram (model/mod.rs:520-528): list of (frames, 128) arrays."""
+    def compute_mel_spectrogram(self, audio: Sequence[np.ndarray], no_alloc: bool = False):
+        """Model::compute_mel_spectrogram (model/mod.rs:520-528): list of (frames, 128) arrays.
+        no_alloc: go through qtts_mel_noalloc (fixed device staging array, no device allocation, bounded batch size)."""
         B = len(audio)
         ns = np.array([len(a) for a in audio], np.int32)
         mx = int(ns.max())
@@ -416,8 +417,9 @@ class Model:
         fs = mx // 256 + 8
         mel = np.zeros((B, fs, 128), np.float32)
         nf = np.zeros(B, np.int32)
-        check(self.lib.qtts_mel(self._m, buf.ctypes.data_as(C.c_void_p), ns.ctypes.data_as(C.c_void_p), B, mx,
-                                mel.ctypes.data_as(C.c_void_p), fs, nf.ctypes.data_as(C.c_void_p)))
+        fn = self.lib.qtts_mel_noalloc if no_alloc else self.lib.qtts_mel
+        check(fn(self._m, buf.ctypes.data_as(C.c_void_p), ns.ctypes.data_as(C.c_void_p), B, mx,
+                 mel.ctypes.data_as(C.c_void_p), fs, nf.ctypes.data_as(C.c_void_p)))
         return [mel[b, :nf[b]].copy() for b in range(B)]
 
     def extract_speaker_embedding(self, audio: Sequence[np.ndarray]) -> np.ndarray:
