@@ -134,6 +134,22 @@ __device__ __forceinline__ void slab_sum_pair(const float* p, int gap, int KS, l
     x2 = a2;
 }
 
+// ---- MFMA operand tiles.  A 16x16xK MFMA operand lane (r = lane & 15, g = lane >> 4) holds, of row r, the two 16-byte pieces
+// 2g and 2g + 1 of every 128-byte row segment ("chunk": 64 bf16 / 32 f32 elements); piece h feeds the h-th MFMA step.
+// Reading them straight from a row-major matrix makes 16 consecutive lanes touch 16 different cache lines, which a CU's
+// vector L1 serves at about a quarter of its line rate (16 B/clk measured against 64 B/clk with eight consecutive lanes on one
+// line), so:
+//  - activations are DMA'd to LDS row-contiguously - instruction h2 of a 16-row x 128-byte unit covers rows 8 h2 .. 8 h2 + 7,
+//    eight lanes per row - with the piece order inside a row XOR-swizzled so that the later ds_read_b128 fragment reads are
+//    bank-conflict free (unit_src_* / unit_slot below);
+//  - weights are re-laid once at load time into fragment order (see WMat in kernels.hpp), one contiguous KiB per wave load.
+__device__ __forceinline__ int unit_swz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 2); }
+// DMA instruction h2 (0/1) of a unit, this lane's source: row within the unit and 16-byte piece within the row segment
+__device__ __forceinline__ int unit_src_row(int lane, int h2) { return 8 * h2 + (lane >> 3); }
+__device__ __forceinline__ int unit_src_piece(int lane, int h2) { return (lane & 7) ^ unit_swz(unit_src_row(lane, h2)); }
+// 16-byte LDS slot (0..127 within the unit's 2 KiB) of piece h of MFMA lane (r, g)
+__device__ __forceinline__ int unit_slot(int r, int g, int h) { return r * 8 + ((2 * g + h) ^ unit_swz(r)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -51,10 +51,6 @@ std::string lower(const char* s) {
     return r;
 }
 
-struct GemmPlan {
-    int N, K, KS;
-};
-
 }  // namespace
 
 struct StackRun {
@@ -84,7 +80,7 @@ struct GenState {
 
 void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling* sp, int max_new, qtts_codes_out* outs,
                   const qtts_gen_debug* dbg) {
-    QTTS_CHECK(m.finalized && m.codec_head != nullptr, ERR_STATE, "generate: model has no talker weights or is not finalized");
+    QTTS_CHECK(m.finalized && m.codec_head.p != nullptr, ERR_STATE, "generate: model has no talker weights or is not finalized");
     QTTS_CHECK(reqs && outs && sp && n >= 1 && n <= 1024, ERR_BAD_ARG, "generate: bad batch");
     QTTS_CHECK(max_new >= 1 && max_new <= 32768, ERR_BAD_ARG, "generate: max_new_tokens out of range");
     QTTS_HIP(hipSetDevice(m.ctx->device));
@@ -233,6 +229,13 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     g.ws.x.ensure(rows * Wmax * 4);
     g.ws.alloc_inputs(rows, (size_t)Wmax, (size_t)QD, (size_t)Imax, es, split);
     R.split(true);  // the runner's copy of the plane offsets follows the allocation
+    // code predictor as five launches per layer (bf16, hidden <= 1024, single-plane activations)
+    const bool fused_cp = Runner::stack_fusable(m, m.cp) && !split_cp && Vc % 64 == 0 && H % 64 == 0;
+    if (fused_cp) {
+        g.ws.ss_ld = (long)fused_rows(2 * B) + 64;
+        g.ws.ssA.ensure((size_t)(Hc / 16 + 1) * g.ws.ss_ld * 4);
+        g.ws.ssB.ensure((size_t)(Hc / 16 + 1) * g.ws.ss_ld * 4);
+    }
     // up to GEMM_MAX_KS split-K slabs for the small-M kernels (at most 512 rows); the large-M kernel writes one [rows][N] matrix
     g.ws.part.ensure(std::max(rows, (size_t)GEMM_MAX_KS * std::min<size_t>(rows, 512)) * (size_t)Nmax * 4);
     g.ws.q.ensure(rows * QD * 4);
@@ -437,8 +440,34 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         // ---- code predictor pass 0: [hidden, embed(cb0)] at positions 0, 1
         // Five layers deep, the code predictor stays within the bf16 tolerance with single-plane activations (split level 2 splits it too)
         R.split(split_cp);
-        const long cxn = R.lo_xn;
         const Tok* ct = g.toks_cp.as<Tok>();
+        if (fused_cp) {
+            // five launches per layer: every GEMM applies its consumer's element-wise work (k_gemm_fused.hip)
+            float* ssA = g.ws.ssA.as<float>();
+            auto enter = [&](const void* rows_t, long rows_lo, const float* rows_f, int M) {  // pass input -> x, xn = T(x * ln1), ssA
+                if (m.proj) return R.k_split_resid(m.proj, rows_t, rows_lo, M, Hc, H, m.proj_b, false, m.cp.layers[0].ln1, ssA);
+                launch_rows_prep(st, dt, rows_f, m.cp.layers[0].ln1, g.ws.x.as<float>(), g.ws.xn.p, 0, ssA, M, Hc);
+                return 1;
+            };
+            auto head = [&](int j, size_t row_off, int nt) {  // lm_head j on the newest position of every row (code_predictor.rs:464,514)
+                FusedEpi e{};
+                e.mode = FUSED_PLAIN; e.ss_in = ssA + row_off; e.ss_ld = g.ws.ss_ld; e.ntiles_in = nt; e.H_in = Hc; e.eps = c.cp.eps;
+                e.out_f32 = g.ws.part.as<float>(); e.ld_out = Vc;
+                R.timed(B, Vc, Hc, [&] { R.wide_gemm(m.cp_head[(size_t)j], (const char*)g.ws.xn.p + row_off * Hc * es, Hc, 0, B, Vc, Hc, e); });
+                trace_cp(j);
+            };
+            int nt = enter(g.cp_in_t.p, lo_cp, g.cp_in_f.as<float>(), 2 * B);
+            nt = R.stack_fused(m.cp, 2 * B, ct, g.cp.kv, nt, false);
+            head(0, (size_t)B, nt);
+            sample(g.ws.part.as<float>(), Vc, 1, false, G > 2 ? m.cp_emb[0] : nullptr, inj, in_dt);
+            for (int j = 1; j < G - 1; ++j) {  // code_predictor.rs:480-527
+                nt = enter(g.ws.act.p, 0, g.ws.q.as<float>(), B);   // embedding rows: exact in the model dtype, no remainder plane
+                nt = R.stack_fused(m.cp, B, ct + 2 * B + (size_t)j * B, g.cp.kv, nt, true);
+                head(j, 0, nt);
+                sample(g.ws.part.as<float>(), Vc, j + 1, false, j + 1 < G - 1 ? m.cp_emb[(size_t)j] : nullptr, inj, in_dt);
+            }
+        } else {
+        const long cxn = R.lo_xn;
         if (m.proj) {
             const int ks = R.ks_for(2 * B, Hc, H);
             R.gemm(m.proj, g.cp_in_t.p, 2 * B, Hc, H, ks, H, lo_cp);
@@ -466,6 +495,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
             R.gemm(m.cp_head[(size_t)j], g.ws.xn.p, B, Vc, Hc, 1, Hc, cxn);
             trace_cp(j);
             sample(g.ws.part.as<float>(), Vc, j + 1, false, j + 1 < G - 1 ? m.cp_emb[(size_t)j] : nullptr, inj, in_dt);
+        }
         }
         // ---- next talker input (talker.rs:461-479 + generation.rs:1096-1106) and its layer-0 norm
         R.split(true);

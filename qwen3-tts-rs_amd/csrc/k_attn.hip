@@ -174,6 +174,36 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KV
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const Tok t = a.toks[m];
     const int ncol = (a.nh + 2 * a.nkv) * D;
+    // The key loop is software-pipelined by hand: a fetch covers NG groups of KPW keys per wave, and the K/V rows (with the
+    // page-table entries in front of them) of the next fetch are in flight while the current one goes through the online softmax.
+    // One group per fetch keeps the block at 120 VGPRs (four blocks per CU instead of three at two groups): with several
+    // batches in flight the extra resident blocks are worth more than the deeper prefetch.
+    // The first fetch is issued before phase 1, so that the cached rows travel while the token's own q/k/v are put together;
+    // the newest key is not in the cache yet and is patched in from LDS (own_key) after the barrier.
+    constexpr int NG = 1;
+    const int gi = lane / LPK, li = lane % LPK;
+    auto fetch = [&](int base, float(&kf)[NG][8], float(&vf)[NG][8]) {
+#pragma unroll
+        for (int n = 0; n < NG; ++n) {
+            const int key = base + n * KPW + gi;
+            const bool cached = key < t.ctx_len - 1;
+            const int pos = t.ctx_start + (cached ? key : 0);
+            load8(kv_ptr<T>(kv, a.layer, t.row, pos, 0, g) + li * 8, kf[n]);
+            load8(kv_ptr<T>(kv, a.layer, t.row, pos, 1, g) + li * 8, vf[n]);
+        }
+    };
+    auto own_key = [&](int base, float(&kf)[NG][8], float(&vf)[NG][8]) {
+#pragma unroll
+        for (int n = 0; n < NG; ++n) {
+            if (base + n * KPW + gi == t.ctx_len - 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { kf[n][e] = kown[li * 8 + e]; vf[n][e] = vown[li * 8 + e]; }
+            }
+        }
+    };
+    float kA[NG][8], vA[NG][8], kB[NG][8], vB[NG][8];
+    const int base0 = wave * NG * KPW;
+    if (base0 < t.ctx_len) fetch(base0, kA, vA);
     // ---- phase 1: k, v and the REP query heads of this kv group (one wave per head, lane = rotation pair)
     for (int hh = wave; hh < 2 + REP; hh += 4) {
         const bool is_k = hh == 0, is_v = hh == 1;
@@ -217,7 +247,6 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KV
     }
     __syncthreads();
     // ---- phase 2: online-softmax attention; the newest key comes from LDS, the rest from the cache
-    const int gi = lane / LPK, li = lane % LPK;
     float qv[REP][8], o[REP][8], mx[REP], l[REP];
 #pragma unroll
     for (int h = 0; h < REP; ++h) {
@@ -226,26 +255,6 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KV
         mx[h] = -1e30f;
         l[h] = 0.f;
     }
-    // The key loop is software-pipelined by hand: a fetch covers NG groups of KPW keys per wave, and the K/V rows (with the
-    // page-table entries in front of them) of the next fetch are in flight while the current one goes through the online softmax.
-    // One group per fetch keeps the block at 120 VGPRs (four blocks per CU instead of three at two groups): with several
-    // batches in flight the extra resident blocks are worth more than the deeper prefetch.
-    constexpr int NG = 1;
-    auto fetch = [&](int base, float(&kf)[NG][8], float(&vf)[NG][8]) {
-#pragma unroll
-        for (int n = 0; n < NG; ++n) {
-            const int key = base + n * KPW + gi;
-            const bool valid = key < t.ctx_len;
-            if (key == t.ctx_len - 1) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { kf[n][e] = kown[li * 8 + e]; vf[n][e] = vown[li * 8 + e]; }
-            } else {
-                const int pos = t.ctx_start + (valid ? key : 0);
-                load8(kv_ptr<T>(kv, a.layer, t.row, pos, 0, g) + li * 8, kf[n]);
-                load8(kv_ptr<T>(kv, a.layer, t.row, pos, 1, g) + li * 8, vf[n]);
-            }
-        }
-    };
     auto accumulate = [&](int base, const float(&kf)[NG][8], const float(&vf)[NG][8]) {
 #pragma unroll
         for (int n = 0; n < NG; ++n) {
@@ -263,22 +272,22 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KV
                 const float p = expf(s - mn);
                 l[h] = l[h] * alpha + p;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[h][e] = o[h][e] * alpha + p * vf[n][e];
+                for (int e = 0; e < 8; ++e) o[h][e] = o[h][e] * alpha + (valid ? p * vf[n][e] : 0.f);  // a padding lane's row is whatever the cache holds
                 mx[h] = mn;
             }
         }
     };
     {
         constexpr int STEP = 4 * NG * KPW;
-        float kA[NG][8], vA[NG][8], kB[NG][8], vB[NG][8];
-        int base = wave * NG * KPW;
-        if (base < t.ctx_len) fetch(base, kA, vA);
+        int base = base0;
         while (base < t.ctx_len) {
             if (base + STEP < t.ctx_len) fetch(base + STEP, kB, vB);
+            own_key(base, kA, vA);
             accumulate(base, kA, vA);
             base += STEP;
             if (base >= t.ctx_len) break;
             if (base + STEP < t.ctx_len) fetch(base + STEP, kA, vA);
+            own_key(base, kB, vB);
             accumulate(base, kB, vB);
             base += STEP;
         }

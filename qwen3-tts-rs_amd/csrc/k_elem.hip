@@ -274,6 +274,29 @@ void launch_embed_sum_norm(hipStream_t st, int dtype, const EmbedSumArgs& a, con
     else throw Error(ERR_BAD_ARG, "embed_sum: embedding and activation dtypes must match");
 }
 
+// First step of the split RMSNorm (nn/norm.rs:17-23) for rows that do not come out of a GEMM: xb = T(x * w) and the row's sum
+// of squares; the consuming GEMM divides by sqrt(ss / H + eps).
+template <typename T>
+__global__ __launch_bounds__(256) void rows_prep_kernel(const float* __restrict__ x, const float* __restrict__ nw, float* x_out, T* xb, long xb_lo,
+                                                        float* ss_out, int H) {
+    __shared__ float red[32];
+    const long row = blockIdx.x;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        const float v = x[row * H + i];
+        if (x_out) x_out[row * H + i] = v;
+        store_split<T>(xb + row * H + i, xb_lo, v * nw[i]);
+        ss += v * v;
+    }
+    const float tot = block_sum(ss, red);
+    if (threadIdx.x == 0) ss_out[row] = tot;
+}
+void launch_rows_prep(hipStream_t st, int dtype, const float* x, const float* nw, float* x_out, void* xb, long xb_lo, float* ss_out, int M, int H) {
+    QTTS_CHECK(M >= 1 && H >= 1 && x && nw && xb && ss_out, ERR_BAD_ARG, "rows_prep: bad argument");
+    if (dtype == BF16) hipLaunchKernelGGL(rows_prep_kernel<bf16_t>, dim3(M), dim3(256), 0, st, x, nw, x_out, (bf16_t*)xb, xb_lo, ss_out, H);
+    else hipLaunchKernelGGL(rows_prep_kernel<float>, dim3(M), dim3(256), 0, st, x, nw, x_out, (float*)xb, 0L, ss_out, H);
+}
+
 // sum_ref_code_embeddings (qwen_tts/src/nn/generation.rs:242-273): dst[rows[i]] = codec_emb[c0] + sum_g cp_emb[g-1][c_g]
 // for reference frames of an ICL prompt; adds run in codebook order in f32.
 template <typename TE>

@@ -23,7 +23,8 @@ namespace qtts {
 // Tuning switches, read from the environment once per process (the first call from any thread fixes them for all).
 struct GemmEnv {
     int force_kind, force_nt, force_nch, min_blocks;
-    bool xcd_order, conv_halo_off, lo_half_rows;
+    bool xcd_order, conv_halo_off;
+    int mt_min;  // smallest row tile count per block the decode GEMM plans may choose (1, 2 or 4)
 };
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
@@ -32,7 +33,7 @@ static int env_int(const char* name, int dflt) {
 static const GemmEnv& gemm_env() {
     static const GemmEnv e{env_int("QTTS_GEMM_KIND", -1), env_int("QTTS_GEMM_NT", 0), env_int("QTTS_GEMM_NCH", 0),
                            env_int("QTTS_GEMM_MIN_BLOCKS", 192), env_int("QTTS_GEMM_XCD", 1) != 0, env_int("QTTS_CONV_HALO", 1) == 0,
-                           env_int("QTTS_GEMM_LO_HALF", 1) != 0};
+                           env_int("QTTS_GEMM_MT_MIN", 4)};
     return e;
 }
 
@@ -43,17 +44,18 @@ struct Frag<bf16_t> {
     static constexpr int CHUNK = 64;  // K elements covered by one wave-wide 32-byte-per-lane load
     static constexpr int EPL = 16;    // elements per lane
     bf16x8_t v[2];
-    __device__ __forceinline__ void load(const bf16_t* p) {
+    // hs: elements between the lane's two 16-byte pieces (8 in a row-major matrix, 64 * 8 in a packed weight tile)
+    __device__ __forceinline__ void load(const bf16_t* p, int hs = 8) {
         v[0] = *reinterpret_cast<const bf16x8_t*>(p);
-        v[1] = *reinterpret_cast<const bf16x8_t*>(p + 8);
+        v[1] = *reinterpret_cast<const bf16x8_t*>(p + hs);
     }
     // weights that one block reads once: non-temporal, so that they do not displace the activations in L2
-    __device__ __forceinline__ void load_stream(const bf16_t* p) {
+    __device__ __forceinline__ void load_stream(const bf16_t* p, int hs = 8) {
         if (QTTS_NT_WEIGHTS) {
             v[0] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(p));
-            v[1] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(p + 8));
+            v[1] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(p + hs));
         } else {
-            load(p);
+            load(p, hs);
         }
     }
     static __device__ __forceinline__ f32x4_t mma(const Frag& a, const Frag& b, f32x4_t c) {
@@ -67,18 +69,18 @@ struct Frag<float> {
     static constexpr int CHUNK = 32;
     static constexpr int EPL = 8;
     float v[8];
-    __device__ __forceinline__ void load(const float* p) {
+    __device__ __forceinline__ void load(const float* p, int hs = 4) {
         const float4 a = *reinterpret_cast<const float4*>(p);
-        const float4 b = *reinterpret_cast<const float4*>(p + 4);
+        const float4 b = *reinterpret_cast<const float4*>(p + hs);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     }
-    __device__ __forceinline__ void load_stream(const float* p) {
+    __device__ __forceinline__ void load_stream(const float* p, int hs = 4) {
         if (QTTS_NT_WEIGHTS) {
             const f32x4_t a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
-            const f32x4_t b = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p + 4));
+            const f32x4_t b = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p + hs));
             v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
         } else {
-            load(p);
+            load(p, hs);
         }
     }
     static __device__ __forceinline__ f32x4_t mma(const Frag& a, const Frag& b, f32x4_t c) {
@@ -88,12 +90,54 @@ struct Frag<float> {
     }
 };
 
+// This lane's fragment of the 16-row weight tile that starts at row n0 (a multiple of 16): chunk c, piece h is at
+// p + c * cs + h * hs elements, in a row-major matrix or a packed one (WMat).
+template <typename T>
+struct WTile {
+    const T* p;
+    int cs, hs;
+    __device__ __forceinline__ WTile() : p(nullptr), cs(0), hs(0) {}
+    __device__ __forceinline__ WTile(const T* W, int n0, int K, int lane, int pk) {
+        constexpr int HALF = 16 / sizeof(T);
+        if (pk) {
+            cs = 128 * HALF;
+            hs = 64 * HALF;
+            p = W + (size_t)(n0 >> 4) * (K / Frag<T>::CHUNK) * cs + lane * HALF;
+        } else {
+            cs = Frag<T>::CHUNK;
+            hs = HALF;
+            p = W + (size_t)(n0 + (lane & 15)) * K + (lane >> 4) * Frag<T>::EPL;
+        }
+    }
+    __device__ __forceinline__ const T* chunk(int c) const { return p + (size_t)c * cs; }
+};
+
+// Asynchronous copy of one 16-row x 128-byte activation unit (rows `row0`.., row stride ldx elements, starting at element
+// column `col`) into the 2 KiB LDS unit `dst`, as two DMA instructions issued by one wave (device_utils.hpp: unit_*).
+template <typename T>
+__device__ __forceinline__ void dma_unit_half(const T* X, long row0, long ldx, long col, int h2, uint4* dst, int lane) {
+    constexpr int HALF = 16 / sizeof(T);
+    const T* src = X + (row0 + unit_src_row(lane, h2)) * ldx + col + unit_src_piece(lane, h2) * HALF;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(dst + h2 * 64), 16, 0, 0);
+}
+// the MFMA operand of lane (r, g) out of an LDS unit
+template <typename T>
+__device__ __forceinline__ Frag<T> unit_frag(const uint4* unit, int s0, int s1) {
+    Frag<T> b;
+    const uint4 h0 = unit[s0];
+    const uint4 h1 = unit[s1];
+    __builtin_memcpy(&b, &h0, 16);
+    __builtin_memcpy((char*)&b + 16, &h1, 16);
+    return b;
+}
+
 // LO: X carries a second plane `x_lo` elements behind it (the rounding remainder of the activations, see
 // device_utils.hpp store_split); both planes are multiplied, so the product sees the activations to ~16 bits.
 template <typename T, int MT, int NT, bool LO>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ W, const T* __restrict__ X,
                                                           float* __restrict__ out, int N, int K, int KS, int ldx,
-                                                          long out_ks_stride, long x_lo) {
+                                                          long out_ks_stride, long x_lo, int wpk) {
     using F = Frag<T>;
     __shared__ f32x4_t red[4][MT * NT][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -104,10 +148,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ 
     const int nC = K / F::CHUNK, S = KS * 4, s = ks * 4 + wave;
     const int c0 = (int)((long)s * nC / S), c1 = (int)((long)(s + 1) * nC / S);
 
-    const T* wp[NT];
+    WTile<T> wp[NT];
     const T* xp[MT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) wp[j] = W + (size_t)(n0 + 16 * j + r) * K + g * F::EPL;
+    for (int j = 0; j < NT; ++j) wp[j] = WTile<T>(W, n0 + 16 * j, K, lane, wpk);
 #pragma unroll
     for (int i = 0; i < MT; ++i) xp[i] = X + (size_t)(row0 + 16 * i + r) * ldx + g * F::EPL;
 
@@ -124,7 +168,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ 
     auto load_stage = [&](F(&a)[NT], F(&b)[MB], int c) {
         const size_t off = (size_t)c * F::CHUNK;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) a[j].load_stream(wp[j] + off);
+        for (int j = 0; j < NT; ++j) a[j].load_stream(wp[j].chunk(c), wp[j].hs);
 #pragma unroll
         for (int i = 0; i < MT; ++i) b[i].load(xp[i] + off);
         if constexpr (LO) {
@@ -178,10 +222,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const T* __restrict__ 
 template <typename T, int MT, int NT, int NCH, bool LO>
 __global__ __launch_bounds__(256) void gemm_ldsx_kernel(const T* __restrict__ W, const T* __restrict__ X,
                                                         float* __restrict__ out, int N, int K, int ldx,
-                                                        long out_ks_stride, int GX, int KS, int Z, long x_lo) {
+                                                        long out_ks_stride, int GX, int KS, int Z, long x_lo, int wpk) {
     using F = Frag<T>;
-    constexpr int HALF = 16 / sizeof(T);  // elements per 16-byte half fragment
-    constexpr int NFB = NCH * MT * 2;      // 1 KiB fragment blocks of one plane
+    constexpr int NFB = NCH * MT * 2;      // 1 KiB half units of one plane
     __shared__ uint4 xs[(LO ? 2 : 1) * NFB * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -201,13 +244,11 @@ __global__ __launch_bounds__(256) void gemm_ldsx_kernel(const T* __restrict__ W,
     const int row0 = bz * (16 * MT);
     const size_t kbeg = (size_t)ks * NCH * F::CHUNK;
 
-    // X fragment blocks -> LDS (asynchronous, no VGPRs); a remainder plane's blocks follow the first plane's in LDS
+    // X units -> LDS (asynchronous, no VGPRs); a remainder plane's units follow the first plane's in LDS
     auto dma_plane = [&](int pl) {
         for (int f = wave; f < NFB; f += 4) {
-            const int c = f / (MT * 2), i = (f >> 1) % MT, h = f & 1;
-            const T* src = X + (pl ? x_lo : 0) + (size_t)(row0 + 16 * i + r) * ldx + kbeg + (size_t)c * F::CHUNK + g * F::EPL + h * HALF;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(xs + (pl * NFB + f) * 64), 16, 0, 0);
+            const int c = f / (MT * 2), i = (f >> 1) % MT, h2 = f & 1;
+            dma_unit_half<T>(X + (pl ? x_lo : 0), row0 + 16 * i, ldx, (long)kbeg + (long)c * F::CHUNK, h2, xs + (pl * NFB + (f & ~1)) * 64, lane);
         }
     };
     dma_plane(0);
@@ -218,9 +259,10 @@ __global__ __launch_bounds__(256) void gemm_ldsx_kernel(const T* __restrict__ W,
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             // one row slice: every weight byte is read by exactly one block (streamed); several: the slices share it through L2
-            const T* wsrc = W + (size_t)(n0 + 16 * j + r) * K + kbeg + (size_t)c * F::CHUNK + g * F::EPL;
-            if (Z > 1) a[c][j].load(wsrc);
-            else a[c][j].load_stream(wsrc);
+            const WTile<T> wt(W, n0 + 16 * j, K, lane, wpk);
+            const T* wsrc = wt.chunk(ks * NCH + c);
+            if (Z > 1) a[c][j].load(wsrc, wt.hs);
+            else a[c][j].load_stream(wsrc, wt.hs);
         }
     if constexpr (LO) dma_plane(1);
 
@@ -231,17 +273,14 @@ __global__ __launch_bounds__(256) void gemm_ldsx_kernel(const T* __restrict__ W,
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's LDS DMA has landed before it signals the barrier
     __syncthreads();
+    const int s0 = unit_slot(r, g, 0), s1 = unit_slot(r, g, 1);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
             for (int pl = 0; pl < (LO ? 2 : 1); ++pl) {
-                F b;
-                const uint4 h0 = xs[(pl * NFB + (c * MT + i) * 2 + 0) * 64 + lane];
-                const uint4 h1 = xs[(pl * NFB + (c * MT + i) * 2 + 1) * 64 + lane];
-                __builtin_memcpy(&b, &h0, 16);
-                __builtin_memcpy((char*)&b + 16, &h1, 16);
+                const F b = unit_frag<T>(xs + (pl * NFB + (c * MT + i) * 2) * 64, s0, s1);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[c][j], b, acc[i][j]);
             }
@@ -256,47 +295,47 @@ __global__ __launch_bounds__(256) void gemm_ldsx_kernel(const T* __restrict__ W,
 }
 
 template <typename T, int MT, int NT, int NCH, bool LO>
-static void launch_ldsx(hipStream_t st, const T* W, const T* X, float* out, int Mpad, int N, int K, int ldx, long x_lo) {
+static void launch_ldsx(hipStream_t st, const T* W, int wpk, const T* X, float* out, int Mpad, int N, int K, int ldx, long x_lo) {
     const int KS = K / (NCH * Frag<T>::CHUNK);
     const int GX = N / (64 * NT), Z = Mpad / (16 * MT);
     const bool xcd_order = gemm_env().xcd_order;
     if (Z > 1 && xcd_order) {
         const int groups = (GX * KS + 7) / 8;
         hipLaunchKernelGGL((gemm_ldsx_kernel<T, MT, NT, NCH, LO>), dim3(groups * 8 * Z), dim3(256), 0, st, W, X, out, N, K, ldx, (long)Mpad * N,
-                           GX, KS, Z, x_lo);
+                           GX, KS, Z, x_lo, wpk);
         return;
     }
     dim3 grid(GX, KS, Z);
-    hipLaunchKernelGGL((gemm_ldsx_kernel<T, MT, NT, NCH, LO>), grid, dim3(256), 0, st, W, X, out, N, K, ldx, (long)Mpad * N, GX, KS, 1, x_lo);
+    hipLaunchKernelGGL((gemm_ldsx_kernel<T, MT, NT, NCH, LO>), grid, dim3(256), 0, st, W, X, out, N, K, ldx, (long)Mpad * N, GX, KS, 1, x_lo, wpk);
 }
 
 template <typename T, int MT, bool LO>
-static bool launch_ldsx_mt(hipStream_t st, const T* W, const T* X, float* out, int Mpad, int N, int K, int ldx, int NT, int NCH, long x_lo) {
-#define QTTS_LDSX(nt, nch) if (NT == nt && NCH == nch) { launch_ldsx<T, MT, nt, nch, LO>(st, W, X, out, Mpad, N, K, ldx, x_lo); return true; }
+static bool launch_ldsx_mt(hipStream_t st, const T* W, int wpk, const T* X, float* out, int Mpad, int N, int K, int ldx, int NT, int NCH, long x_lo) {
+#define QTTS_LDSX(nt, nch) if (NT == nt && NCH == nch) { launch_ldsx<T, MT, nt, nch, LO>(st, W, wpk, X, out, Mpad, N, K, ldx, x_lo); return true; }
     QTTS_LDSX(1, 4) QTTS_LDSX(1, 8) QTTS_LDSX(2, 4) QTTS_LDSX(2, 8)
-    if constexpr (MT <= 2 && !LO) { QTTS_LDSX(1, 16) }
+    if constexpr (MT <= 2) { QTTS_LDSX(1, 16) }
 #undef QTTS_LDSX
     return false;
 }
 
 template <typename T, int MT, bool LO>
-static void launch_mt(hipStream_t st, const T* W, const T* X, float* out, int Mpad, int N, int K, int KS, int ldx, long x_lo) {
+static void launch_mt(hipStream_t st, const T* W, int wpk, const T* X, float* out, int Mpad, int N, int K, int KS, int ldx, long x_lo) {
     const int Z = Mpad / (16 * MT);
     const long kstride = (long)Mpad * N;
     if (N % 32 == 0 && (long)(N / 32) * KS * Z >= 256) {
         dim3 grid(N / 32, KS, Z);
-        hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 2, LO>), grid, dim3(256), 0, st, W, X, out, N, K, KS, ldx, kstride, x_lo);
+        hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 2, LO>), grid, dim3(256), 0, st, W, X, out, N, K, KS, ldx, kstride, x_lo, wpk);
     } else {
         dim3 grid(N / 16, KS, Z);
-        hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 1, LO>), grid, dim3(256), 0, st, W, X, out, N, K, KS, ldx, kstride, x_lo);
+        hipLaunchKernelGGL((gemm_skinny_kernel<T, MT, 1, LO>), grid, dim3(256), 0, st, W, X, out, N, K, KS, ldx, kstride, x_lo, wpk);
     }
 }
 
 template <typename T, bool LO>
-static void launch_t(hipStream_t st, const T* W, const T* X, float* out, int Mpad, int N, int K, int KS, int ldx, long x_lo) {
-    if (Mpad == 16) launch_mt<T, 1, LO>(st, W, X, out, Mpad, N, K, KS, ldx, x_lo);
-    else if (Mpad == 32) launch_mt<T, 2, LO>(st, W, X, out, Mpad, N, K, KS, ldx, x_lo);
-    else launch_mt<T, 4, LO>(st, W, X, out, Mpad, N, K, KS, ldx, x_lo);
+static void launch_t(hipStream_t st, const T* W, int wpk, const T* X, float* out, int Mpad, int N, int K, int KS, int ldx, long x_lo) {
+    if (Mpad == 16) launch_mt<T, 1, LO>(st, W, wpk, X, out, Mpad, N, K, KS, ldx, x_lo);
+    else if (Mpad == 32) launch_mt<T, 2, LO>(st, W, wpk, X, out, Mpad, N, K, KS, ldx, x_lo);
+    else launch_mt<T, 4, LO>(st, W, wpk, X, out, Mpad, N, K, KS, ldx, x_lo);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -309,10 +348,9 @@ static void launch_t(hipStream_t st, const T* W, const T* X, float* out, int Mpa
 template <typename T, int NT, int NCH, bool EPI, bool LO>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(const T* __restrict__ W, const T* __restrict__ X,
                                                         float* __restrict__ out, int N, int K, int ldx, int cpt,
-                                                        long tap_stride, long row_base, ConvEpi e, long x_lo) {
+                                                        long tap_stride, long row_base, ConvEpi e, long x_lo, int wpk) {
     using F = Frag<T>;
     constexpr int MT = 4;
-    constexpr int HALF = 16 / sizeof(T);
     constexpr int NFB = NCH * MT * 2;
     __shared__ uint4 xs[(LO ? 2 : 1) * NFB * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -325,42 +363,36 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const T* __restrict__ W,
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int s0 = unit_slot(r, g, 0), s1 = unit_slot(r, g, 1);
+    WTile<T> wt[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wt[j] = WTile<T>(W, n0 + 16 * j, K, lane, wpk);
     for (int c0 = 0; c0 < nC; c0 += NCH) {
         for (int fb = wave; fb < (LO ? 2 : 1) * NFB; fb += 4) {
             const int pl = fb / NFB, f = fb % NFB;
-            const int c = f / (MT * 2), i = (f >> 1) % MT, h = f & 1;
+            const int c = f / (MT * 2), i = (f >> 1) % MT, h2 = f & 1;
             const int cg = c0 + c;
-            const T* src = X + (pl ? x_lo : 0) + (row0 + 16 * i + r) * ldx + (long)(cg / cpt) * tap_stride + (long)(cg % cpt) * F::CHUNK +
-                           g * F::EPL + h * HALF;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(xs + fb * 64), 16, 0, 0);
+            dma_unit_half<T>(X + (pl ? x_lo : 0), row0 + 16 * i, ldx, (long)(cg / cpt) * tap_stride + (long)(cg % cpt) * F::CHUNK, h2,
+                             xs + (fb & ~1) * 64, lane);
         }
         F a[NCH][NT];
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-                a[c][j].load(W + (size_t)(n0 + 16 * j + r) * K + (size_t)(c0 + c) * F::CHUNK + g * F::EPL);
+            for (int j = 0; j < NT; ++j) a[c][j].load(wt[j].chunk(c0 + c), wt[j].hs);
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's LDS DMA has landed before it signals the barrier
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                F b;
-                const uint4 h0 = xs[((c * MT + i) * 2 + 0) * 64 + lane];
-                const uint4 h1 = xs[((c * MT + i) * 2 + 1) * 64 + lane];
-                __builtin_memcpy(&b, &h0, 16);
-                __builtin_memcpy((char*)&b + 16, &h1, 16);
+                const F b = unit_frag<T>(xs + ((c * MT + i) * 2) * 64, s0, s1);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[c][j], b, acc[i][j]);
                 if constexpr (LO) {
-                    const uint4 l0 = xs[(NFB + (c * MT + i) * 2 + 0) * 64 + lane];
-                    const uint4 l1 = xs[(NFB + (c * MT + i) * 2 + 1) * 64 + lane];
-                    __builtin_memcpy(&b, &l0, 16);
-                    __builtin_memcpy((char*)&b + 16, &l1, 16);
+                    const F bl = unit_frag<T>(xs + (NFB + (c * MT + i) * 2) * 64, s0, s1);
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[c][j], b, acc[i][j]);
+                    for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[c][j], bl, acc[i][j]);
                 }
             }
         }
@@ -390,7 +422,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const T* __restrict__ W,
 }
 
 template <typename T, bool EPI, bool LO = false>
-static void launch_rows_t(hipStream_t st, const T* W, const T* X, float* out, long Mpad, int N, int K, int ldx, int cpt, long tap_stride,
+static void launch_rows_t(hipStream_t st, const T* W, int wpk, const T* X, float* out, long Mpad, int N, int K, int ldx, int cpt, long tap_stride,
                           const ConvEpi& e, long x_lo = 0) {
     const int nC = K / Frag<T>::CHUNK;
     // out rows are relative to the launch: split launches at the grid.y limit
@@ -400,7 +432,7 @@ static void launch_rows_t(hipStream_t st, const T* W, const T* X, float* out, lo
         const int gy = (int)(rows / 64);
 #define QTTS_ROWS(nt, nch)                                                                                                          \
     hipLaunchKernelGGL((gemm_rows_kernel<T, nt, nch, EPI, LO>), dim3(N / (64 * nt), gy), dim3(256), 0, st, W, X, o, N, K, ldx, cpt, \
-                       tap_stride, base, e, x_lo)
+                       tap_stride, base, e, x_lo, wpk)
         if (N % 128 == 0) {
             if (nC % 4 == 0) QTTS_ROWS(2, 4);
             else if (nC % 3 == 0) QTTS_ROWS(2, 3);
@@ -417,8 +449,10 @@ static void launch_rows_t(hipStream_t st, const T* W, const T* X, float* out, lo
 }
 
 // out[m][n] = sum over taps/channels; M rows padded up to 64 must be readable in X (including the tap offsets).
-void launch_gemm_rows(hipStream_t st, int dtype, const void* W, const void* X, float* out, long M, int N, int K, int ldx, int taps,
+void launch_gemm_rows(hipStream_t st, int dtype, WMat Wm, const void* X, float* out, long M, int N, int K, int ldx, int taps,
                       long tap_stride, long x_lo) {
+    const void* W = Wm.p;
+    const int wpk = Wm.packed ? 1 : 0;
     QTTS_CHECK(M >= 1 && N % 64 == 0 && taps >= 1 && K % taps == 0, ERR_SHAPE, "gemm_rows: N must be a multiple of 64");
     const int chunk = dtype == BF16 ? 64 : 32;
     QTTS_CHECK((K / taps) % chunk == 0, ERR_SHAPE, "gemm_rows: channels per tap must be a multiple of the K chunk");
@@ -426,14 +460,16 @@ void launch_gemm_rows(hipStream_t st, int dtype, const void* W, const void* X, f
     const int cpt = K / taps / chunk;
     const ConvEpi none{};
     QTTS_CHECK(x_lo == 0 || dtype == BF16, ERR_BAD_ARG, "gemm_rows: a remainder plane exists for bf16 activations only");
-    if (dtype == BF16 && x_lo) launch_rows_t<bf16_t, false, true>(st, (const bf16_t*)W, (const bf16_t*)X, out, Mpad, N, K, ldx, cpt, tap_stride, none, x_lo);
-    else if (dtype == BF16) launch_rows_t<bf16_t, false>(st, (const bf16_t*)W, (const bf16_t*)X, out, Mpad, N, K, ldx, cpt, tap_stride, none);
-    else launch_rows_t<float, false>(st, (const float*)W, (const float*)X, out, Mpad, N, K, ldx, cpt, tap_stride, none);
+    if (dtype == BF16 && x_lo) launch_rows_t<bf16_t, false, true>(st, (const bf16_t*)W, wpk, (const bf16_t*)X, out, Mpad, N, K, ldx, cpt, tap_stride, none, x_lo);
+    else if (dtype == BF16) launch_rows_t<bf16_t, false>(st, (const bf16_t*)W, wpk, (const bf16_t*)X, out, Mpad, N, K, ldx, cpt, tap_stride, none);
+    else launch_rows_t<float, false>(st, (const float*)W, wpk, (const float*)X, out, Mpad, N, K, ldx, cpt, tap_stride, none);
 }
 
 // Same GEMM with the conv epilogue applied in registers (no f32 output): e.acc is ignored, e.M bounds the rows.
-void launch_gemm_rows_epi(hipStream_t st, int dtype, const void* W, const void* X, int K, int ldx, int taps, long tap_stride,
+void launch_gemm_rows_epi(hipStream_t st, int dtype, WMat Wm, const void* X, int K, int ldx, int taps, long tap_stride,
                           const ConvEpi& e, long x_lo) {
+    const void* W = Wm.p;
+    const int wpk = Wm.packed ? 1 : 0;
     const long M = e.M;
     const int N = e.N;
     QTTS_CHECK(M >= 1 && N % 64 == 0 && taps >= 1 && K % taps == 0, ERR_SHAPE, "gemm_rows: N must be a multiple of 64");
@@ -443,47 +479,57 @@ void launch_gemm_rows_epi(hipStream_t st, int dtype, const void* W, const void* 
     const int chunk = dtype == BF16 ? 64 : 32;
     QTTS_CHECK((K / taps) % chunk == 0, ERR_SHAPE, "gemm_rows: channels per tap must be a multiple of the K chunk");
     QTTS_CHECK(x_lo == 0 || dtype == BF16, ERR_BAD_ARG, "gemm_rows: a remainder plane exists for bf16 activations only");
-    if (x_lo == 0 && !gemm_env().conv_halo_off && launch_conv_halo(st, dtype, W, X, K, ldx, taps, tap_stride, e)) return;
+    if (x_lo == 0 && !wpk && !gemm_env().conv_halo_off && launch_conv_halo(st, dtype, W, X, K, ldx, taps, tap_stride, e)) return;
     const long Mpad = (M + 63) / 64 * 64;
     const int cpt = K / taps / chunk;
-    if (dtype == BF16 && x_lo) launch_rows_t<bf16_t, true, true>(st, (const bf16_t*)W, (const bf16_t*)X, nullptr, Mpad, N, K, ldx, cpt, tap_stride, e, x_lo);
-    else if (dtype == BF16) launch_rows_t<bf16_t, true>(st, (const bf16_t*)W, (const bf16_t*)X, nullptr, Mpad, N, K, ldx, cpt, tap_stride, e);
-    else launch_rows_t<float, true>(st, (const float*)W, (const float*)X, nullptr, Mpad, N, K, ldx, cpt, tap_stride, e);
+    if (dtype == BF16 && x_lo) launch_rows_t<bf16_t, true, true>(st, (const bf16_t*)W, wpk, (const bf16_t*)X, nullptr, Mpad, N, K, ldx, cpt, tap_stride, e, x_lo);
+    else if (dtype == BF16) launch_rows_t<bf16_t, true>(st, (const bf16_t*)W, wpk, (const bf16_t*)X, nullptr, Mpad, N, K, ldx, cpt, tap_stride, e);
+    else launch_rows_t<float, true>(st, (const float*)W, wpk, (const float*)X, nullptr, Mpad, N, K, ldx, cpt, tap_stride, e);
 }
 
 int gemm_pad_rows(int M) { return M <= 16 ? 16 : (M <= 32 ? 32 : (M + 63) / 64 * 64); }
 
 // Picks the kernel variant and the split-K factor for a shape.  Deterministic in (M, N, K, dtype) so that the
 // consumers of the partial slabs can recompute KS.
+//
+// LDS-shared-X kernel: a block owns 64*NT weight rows x NCH K-chunks for a slice of 16*MT token rows.  Slab traffic
+// (KS * M * N * 4 bytes written, then read back by the consumer) falls with NCH; the block count (N / (64 NT)) * KS * Z,
+// Z = Mpad / (16 MT), is kept up by cutting the rows into more slices instead of the K range into more slabs: the slices of
+// one weight tile run on one XCD and share the tile through its L2, so HBM still streams every weight byte once.
 GemmPlan gemm_plan(int M, int N, int K, int dtype) {
     const GemmEnv& env = gemm_env();
     const int force_kind = env.force_kind, force_nt = env.force_nt, force_nch = env.force_nch;
-    // first candidate (fewest slabs first) that still gives this many blocks: 192 measured best (fewer slab bytes to write and
-    // read back; with several batches in flight the other streams fill the CUs a smaller grid leaves idle)
+    // first candidate (fewest slabs first) that still gives this many blocks
     const int min_blocks = env.min_blocks;
     const int chunk = dtype == BF16 ? 64 : 32;
     const int nC = K / chunk;
     const int Mpad = gemm_pad_rows(M);
-    const int Z = Mpad <= 32 ? 1 : Mpad / 64;
-    GemmPlan p{1, 0, 1, 0};
+    GemmPlan p{1, 0, 1, 0, 4};
     if (Mpad >= 32 && force_kind != 0) {
-        // LDS-shared X: candidates ordered by preference (fewest slabs / most X reuse first)
-        const int cand[][2] = {{2, 8}, {1, 8}, {2, 4}, {1, 4}};
+        const int mt_hi = Mpad == 32 ? 2 : 4;
+        const int mt_lo = Mpad > 64 ? 4 : std::max(1, std::min(env.mt_min, mt_hi));
         long best_blocks = -1;
-        for (auto& cnd : cand) {
-            const int nt = cnd[0], nch = cnd[1];
-            if (force_nt && nt != force_nt) continue;
+        for (int nch : {16, 8, 4}) {
             if (force_nch && nch != force_nch) continue;
-            if (N % (64 * nt) != 0 || nC % nch != 0) continue;
+            if (nC % nch != 0) continue;
             const int ks = nC / nch;
             if (ks > GEMM_MAX_KS) continue;
-            const long blocks = (long)(N / (64 * nt)) * ks * Z;
-            if (blocks >= min_blocks) { p = GemmPlan{ks, 1, nt, nch}; return p; }
-            if (blocks > best_blocks) { best_blocks = blocks; p = GemmPlan{ks, 1, nt, nch}; }
+            for (int mt = mt_hi; mt >= mt_lo; mt >>= 1) {
+                if (nch * mt > 32) continue;  // X tile (two planes in bf16 runs) within 128 KB of LDS
+                for (int nt : {2, 1}) {
+                    if (force_nt && nt != force_nt) continue;
+                    if (nch * nt > 16) continue;  // weight fragments of the whole K range live in registers
+                    if (N % (64 * nt) != 0) continue;
+                    const long blocks = (long)(N / (64 * nt)) * ks * (Mpad / (16 * mt));
+                    if (blocks >= min_blocks) return GemmPlan{ks, 1, nt, nch, mt};
+                    if (blocks > best_blocks) { best_blocks = blocks; p = GemmPlan{ks, 1, nt, nch, mt}; }
+                }
+            }
         }
         if (best_blocks >= 128 || force_kind == 1) { if (p.kind == 1) return p; }
-        p = GemmPlan{1, 0, 1, 0};
+        p = GemmPlan{1, 0, 1, 0, 4};
     }
+    const int Z = Mpad <= 32 ? 1 : Mpad / 64;
     const long nblk = (long)(N / 16) * Z;  // blocks at KS = 1 with one 16-row tile each
     int ks = 1;
     // aim for >= ~512 blocks (2 per CU) while every wave keeps at least two chunks
@@ -497,32 +543,51 @@ GemmPlan gemm_plan(int M, int N, int K, int dtype) {
 int gemm_pick_ks(int M, int N, int K, int dtype) { return gemm_plan(M, N, K, dtype).KS; }
 
 template <typename T, bool LO>
-static void launch_plan(hipStream_t st, const GemmPlan& p, const T* W, const T* X, float* out, int Mpad, int N, int K, int ldx, long x_lo) {
+static void launch_plan(hipStream_t st, const GemmPlan& p, const T* W, int wpk, const T* X, float* out, int Mpad, int N, int K, int ldx, long x_lo) {
     if (p.kind == 1) {
         bool ok = false;
-        // with a remainder plane the X tile of 64 rows x 8 chunks fills 128 KB of LDS (one block per CU): 32-row slices
-        // halve it, and the two slices of a weight tile share it through their XCD's L2
-        // (worth it where one 64-row block per CU would need a second round: more than 256 blocks)
-        const bool half_rows = LO && p.NCH >= 8 && Mpad == 64 && (long)(N / (64 * p.NT)) * p.KS > 256 && gemm_env().lo_half_rows;
-        if (Mpad == 32 || half_rows) ok = launch_ldsx_mt<T, 2, LO>(st, W, X, out, Mpad, N, K, ldx, p.NT, p.NCH, x_lo);
-        else ok = launch_ldsx_mt<T, 4, LO>(st, W, X, out, Mpad, N, K, ldx, p.NT, p.NCH, x_lo);
+        if (p.MT == 1) ok = launch_ldsx_mt<T, 1, LO>(st, W, wpk, X, out, Mpad, N, K, ldx, p.NT, p.NCH, x_lo);
+        else if (p.MT == 2) ok = launch_ldsx_mt<T, 2, LO>(st, W, wpk, X, out, Mpad, N, K, ldx, p.NT, p.NCH, x_lo);
+        else ok = launch_ldsx_mt<T, 4, LO>(st, W, wpk, X, out, Mpad, N, K, ldx, p.NT, p.NCH, x_lo);
         QTTS_CHECK(ok, ERR_STATE, "gemm: no kernel instance for the planned variant");
         return;
     }
-    launch_t<T, LO>(st, W, X, out, Mpad, N, K, p.KS, ldx, x_lo);
+    launch_t<T, LO>(st, W, wpk, X, out, Mpad, N, K, p.KS, ldx, x_lo);
 }
 
-void launch_gemm(hipStream_t st, int dtype, const void* W, const void* X, float* out, int M, int N, int K, int KS, int ldx, long x_lo) {
+void launch_gemm(hipStream_t st, int dtype, WMat Wm, const void* X, float* out, int M, int N, int K, int KS, int ldx, long x_lo) {
+    const void* W = Wm.p;
+    const int wpk = Wm.packed ? 1 : 0;
     QTTS_CHECK(N % 16 == 0, ERR_SHAPE, "gemm: N must be a multiple of 16");
     QTTS_CHECK(K % 64 == 0, ERR_SHAPE, "gemm: K must be a multiple of 64");
     QTTS_CHECK(KS >= 1 && M >= 1, ERR_SHAPE, "gemm: bad M/KS");
     QTTS_CHECK(x_lo == 0 || dtype == BF16, ERR_BAD_ARG, "gemm: a remainder plane exists for bf16 activations only");
     const int Mpad = gemm_pad_rows(M);
     GemmPlan p = gemm_plan(M, N, K, dtype);
-    if (p.KS != KS) p = GemmPlan{KS, 0, 1, 0};  // caller forced a split factor: generic kernel
-    if (dtype == BF16 && x_lo) launch_plan<bf16_t, true>(st, p, (const bf16_t*)W, (const bf16_t*)X, out, Mpad, N, K, ldx, x_lo);
-    else if (dtype == BF16) launch_plan<bf16_t, false>(st, p, (const bf16_t*)W, (const bf16_t*)X, out, Mpad, N, K, ldx, 0);
-    else launch_plan<float, false>(st, p, (const float*)W, (const float*)X, out, Mpad, N, K, ldx, 0);
+    if (p.KS != KS) p = GemmPlan{KS, 0, 1, 0, 4};  // caller forced a split factor: generic kernel
+    if (dtype == BF16 && x_lo) launch_plan<bf16_t, true>(st, p, (const bf16_t*)W, wpk, (const bf16_t*)X, out, Mpad, N, K, ldx, x_lo);
+    else if (dtype == BF16) launch_plan<bf16_t, false>(st, p, (const bf16_t*)W, wpk, (const bf16_t*)X, out, Mpad, N, K, ldx, 0);
+    else launch_plan<float, false>(st, p, (const float*)W, wpk, (const float*)X, out, Mpad, N, K, ldx, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-major weight matrix -> fragment order (WMat), 16 bytes per thread.
+__global__ __launch_bounds__(256) void pack_weight_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long pieces, int ppr) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;   // source piece: row n, piece q of the row
+    if (i >= pieces) return;
+    const long n = i / ppr;
+    const int q = (int)(i - n * ppr);
+    const int c = q >> 3, pp = q & 7;
+    const long nC = ppr >> 3;
+    const long d = ((((n >> 4) * nC + c) * 2 + (pp & 1)) * 64) + (n & 15) + 16 * (pp >> 1);
+    dst[d] = src[i];
+}
+void launch_pack_weight(hipStream_t st, const void* src, void* dst, int N, long row_bytes) {
+    QTTS_CHECK(N >= 16 && N % 16 == 0 && row_bytes >= 128 && row_bytes % 128 == 0, ERR_SHAPE, "pack_weight: N must be a multiple of 16 and rows of 128 bytes");
+    QTTS_CHECK(src != dst, ERR_BAD_ARG, "pack_weight: in-place packing is not supported");
+    const long pieces = (long)N * (row_bytes / 16);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, pieces,
+                       (int)(row_bytes / 16));
 }
 
 }  // namespace qtts

@@ -22,8 +22,22 @@ struct KVView {
 };
 
 // ---- k_gemm.hip
+// A GEMM weight matrix W[N][K] (model dtype).  Row-major as loaded, or "packed" by launch_pack_weight into MFMA fragment
+// order: in 16-byte pieces, piece pp (0..7) of the c-th 128-byte segment of row n lives at piece index
+//   (((n / 16) * nC + c) * 2 + (pp & 1)) * 64 + (n % 16) + 16 * (pp >> 1),      nC = K * elem_size / 128,
+// so that a wave's fragment load of a 16-row tile is one contiguous KiB.  N % 16 == 0 and K * elem_size % 128 == 0.
+struct WMat {
+    const void* p = nullptr;
+    bool packed = false;
+    WMat() = default;
+    WMat(const void* q, bool pk = false) : p(q), packed(pk) {}
+    explicit operator bool() const { return p != nullptr; }
+};
+void launch_pack_weight(hipStream_t st, const void* src, void* dst, int N, long row_bytes);
+
 struct GemmPlan {
     int KS, kind, NT, NCH;  // kind 0: in-block split-K kernel, 1: LDS-shared-X kernel
+    int MT;                 // kind 1: 16-row tiles per block (the rows are cut into Mpad / (16 MT) slices)
 };
 constexpr int GEMM_MAX_KS = 16;  // most split-K slabs a plan may ask for; the slab workspaces are sized for it
 int gemm_pad_rows(int M);
@@ -32,12 +46,47 @@ int gemm_pick_ks(int M, int N, int K, int dtype);
 // out is [KS][gemm_pad_rows(M)][N] f32 partial sums; X has gemm_pad_rows(M) readable rows of ldx elements.
 // x_lo != 0 (bf16 only): X carries a remainder plane x_lo elements behind it and both planes are multiplied, so that the
 // activations enter the product with about 16 significant bits (the weights stay plain bf16).
-void launch_gemm(hipStream_t st, int dtype, const void* W, const void* X, float* out, int M, int N, int K, int KS, int ldx,
+void launch_gemm(hipStream_t st, int dtype, WMat W, const void* X, float* out, int M, int N, int K, int KS, int ldx,
                  long x_lo = 0);
 // Large-M GEMM with convolution addressing: out[m][n] = sum_{tap, c} X[m*ldx + tap*tap_stride + c] * W[n][tap*C + c], C = K / taps.
 // out is [ceil64(M)][N] f32; X must be readable for ceil64(M) rows plus the tap offsets.
-void launch_gemm_rows(hipStream_t st, int dtype, const void* W, const void* X, float* out, long M, int N, int K, int ldx, int taps,
+void launch_gemm_rows(hipStream_t st, int dtype, WMat W, const void* X, float* out, long M, int N, int K, int ldx, int taps,
                       long tap_stride, long x_lo = 0);
+
+// ---- k_gemm_fused.hip: decode GEMMs that own finished outputs and apply the consumer's element-wise work (bf16, hidden <= 1024)
+enum { FUSED_PLAIN = 0, FUSED_SWIGLU = 1, FUSED_RESID = 2 };
+struct FusedEpi {
+    int mode;
+    // full_k (PLAIN / SWIGLU): finished sums are multiplied by 1 / sqrt(sum_t ss_in[t][row] / H_in + eps) (no scale when ss_in is null)
+    const float* ss_in;   // [ntiles_in][ss_ld]
+    long ss_ld;           // row stride of ss_in / ss_out
+    int ntiles_in, H_in;
+    float eps;
+    const float* bias;    // [N] or null (PLAIN, RESID)
+    float* out_f32;       // PLAIN: [rows][ld_out]
+    int ld_out;
+    void* act;            // SWIGLU: [rows][N / 2] bf16 (+ remainder plane act_lo elements behind, 0 = none)
+    long act_lo;
+    // k_split (RESID): x = [resid +] sum + bias ; xb = bf16(x * nw) (+ remainder plane) ; ss_out[tile][row] = sum over the tile's 16 columns of x^2
+    const float* resid;   // [rows][N] f32 or null (may alias x_out)
+    float* x_out;         // [rows][N] f32
+    void* xb_out;         // [rows][N] bf16
+    long xb_lo;
+    const float* nw;      // [N] norm weight of the consumer
+    float* ss_out;        // [N / 16][ss_ld]
+};
+bool fused_gemm_supported(int dtype, int hidden);
+int fused_rows(int M);           // rows the kernels read and write for M tokens (16, 32 or a multiple of 64)
+int fused_resid_tiles(int N);    // tiles a RESID launch writes to ss_out
+// W rows for SWIGLU: every 16 rows = [4 gate, 4 up, 4 gate, 4 up] of eight consecutive channels
+// full_k takes K <= 2048 as long as a 16-row X tile (both planes when x_lo != 0) fits LDS: full_k_fits
+bool full_k_fits(int K, bool lo);
+void launch_gemm_full_k(hipStream_t st, WMat W, const void* X, int ldx, long x_lo, int M, int N, int K, const FusedEpi& e);
+// same contract as full_k for 64-row multiples and K = 1024 or 2048: K is walked in double-buffered phases inside the block
+bool gemm_stream_fits(int M, int N, int K, bool lo);
+bool gemm_stream_preferred(int M, int N, int K, bool lo);  // it fits and is the faster kernel for the shape
+void launch_gemm_stream(hipStream_t st, WMat W, const void* X, int ldx, long x_lo, int M, int N, int K, const FusedEpi& e);
+void launch_gemm_k_split(hipStream_t st, WMat W, const void* X, int ldx, long x_lo, int M, int N, int K, const FusedEpi& e);
 
 // ---- k_bench.hip (diagnostics)
 void launch_stream(hipStream_t st, const void* src, unsigned* sink, long bytes, int blocks, int pattern, int unroll, int ld_bytes);
@@ -83,6 +132,9 @@ struct EmbedSumArgs {
 };
 void launch_embed_sum_norm(hipStream_t st, int dtype, const EmbedSumArgs& a, const float* norm_w, float eps, float* resid_out,
                            void* xn, long xn_lo = 0);
+// fused decode stacks: x (f32 rows) -> xb = T(x * nw) (+ remainder plane), ss_out[row] = sum x^2 (one norm partial tile)
+// x_out (optional) receives a copy of x
+void launch_rows_prep(hipStream_t st, int dtype, const float* x, const float* nw, float* x_out, void* xb, long xb_lo, float* ss_out, int M, int H);
 // code-predictor input rows: dst[b] = table[codes[b][g]] cast to dtype (codes laid out as in EmbedSumArgs)
 void launch_gather_codes(hipStream_t st, const void* table, int tdtype, const unsigned* codes_base, long row_stride,
                          const int* step, int G, int g, void* dst, int ddtype, int B, int H);
@@ -173,7 +225,7 @@ struct ConvEpi {
 void launch_conv_epilogue(hipStream_t st, int dtype, const ConvEpi& e);
 // GEMM + epilogue in one launch (k_gemm.hip): rows e.M, columns e.N; e.acc is not used
 // x_lo != 0: X carries a remainder plane (tap-addressed kernel only)
-void launch_gemm_rows_epi(hipStream_t st, int dtype, const void* W, const void* X, int K, int ldx, int taps, long tap_stride,
+void launch_gemm_rows_epi(hipStream_t st, int dtype, WMat W, const void* X, int K, int ldx, int taps, long tap_stride,
                           const ConvEpi& e, long x_lo = 0);
 // k_conv.hip: same contract with the input tile held in LDS; false = shape not covered (use launch_gemm_rows_epi).
 // X must be readable for CONV_HALO_SLACK rows past e.M.

@@ -211,11 +211,37 @@ void Model::ensure_rope(StackW& s, int max_pos) {
     s.max_pos = n;
 }
 
-void build_stack(Model& m, StackW& s, const StackCfg& c, const std::string& prefix, bool qk_norm, bool layer_scale) {
+// GEMM weights are re-laid into MFMA fragment order once, here (kernels.hpp WMat); QTTS_PACK_WEIGHTS=0 keeps them row-major.
+static bool pack_weights_enabled() {
+    static const bool on = !(getenv("QTTS_PACK_WEIGHTS") && atoi(getenv("QTTS_PACK_WEIGHTS")) == 0);
+    return on;
+}
+WMat pack_matrix(Model& m, const void* src, int64_t N, int64_t K) {
+    const size_t es = dtype_size(m.dtype);
+    if (!pack_weights_enabled() || N % 16 != 0 || (K * (int64_t)es) % 128 != 0) return WMat(src, false);
+    DevBuf d;
+    d.alloc((size_t)N * K * es);
+    launch_pack_weight(m.ctx->stream, src, d.p, (int)N, (long)(K * es));
+    WMat w(d.p, true);
+    m.owned.push_back(std::move(d));
+    return w;
+}
+// packs a matrix loaded under `key` and marks the row-major copy for release
+static WMat pack_raw(Model& m, const std::string& key, std::vector<std::string>& release) {
+    const Tensor& t = m.get(key);
+    QTTS_CHECK(t.shape.size() == 2, ERR_SHAPE, ("weight " + key + " is not a matrix").c_str());
+    const WMat w = pack_matrix(m, m.mat(key), t.shape[0], t.shape[1]);
+    if (w.packed) release.push_back(key);
+    return w;
+}
+
+void build_stack(Model& m, StackW& s, const StackCfg& c, const std::string& prefix, bool qk_norm, bool layer_scale, bool fused_layout) {
     s.cfg = c;
     s.layers.resize((size_t)c.layers);
     const size_t es = dtype_size(m.dtype);
     hipStream_t st = m.ctx->stream;
+    std::vector<std::string> release;
+    std::vector<DevBuf> staging;  // row-major fused matrices, dropped once packed
     for (int l = 0; l < c.layers; ++l) {
         const std::string p = prefix + "layers." + std::to_string(l) + ".";
         LayerW& w = s.layers[(size_t)l];
@@ -238,12 +264,27 @@ void build_stack(Model& m, StackW& s, const StackCfg& c, const std::string& pref
         gu.alloc((size_t)2 * c.inter * c.hidden * es);
         QTTS_HIP(hipMemcpyAsync(gu.p, m.mat(p + "mlp.gate_proj.weight"), (size_t)c.inter * c.hidden * es, hipMemcpyDeviceToDevice, st));
         QTTS_HIP(hipMemcpyAsync((char*)gu.p + (size_t)c.inter * c.hidden * es, m.mat(p + "mlp.up_proj.weight"), (size_t)c.inter * c.hidden * es, hipMemcpyDeviceToDevice, st));
-        w.qkv = qkv.p;
-        w.gate_up = gu.p;
-        m.owned.push_back(std::move(qkv));
-        m.owned.push_back(std::move(gu));
-        w.o = m.mat(p + "self_attn.o_proj.weight");
-        w.down = m.mat(p + "mlp.down_proj.weight");
+        if (fused_layout && fused_gemm_supported(m.dtype, c.hidden)) {
+            // rows [4 gate, 4 up, 4 gate, 4 up, ...]: the lanes that hold a gate value and the matching up value of one
+            // token are then 16 apart in the MFMA result of a 16-row tile (k_gemm_fused.hip)
+            QTTS_CHECK(c.inter % 8 == 0, ERR_SHAPE, "intermediate size must be a multiple of 8");
+            DevBuf il;
+            il.alloc((size_t)2 * c.inter * c.hidden * es);
+            const size_t grp = (size_t)4 * c.hidden * es;
+            QTTS_HIP(hipMemcpy2DAsync(il.p, 2 * grp, m.mat(p + "mlp.gate_proj.weight"), grp, grp, (size_t)c.inter / 4, hipMemcpyDeviceToDevice, st));
+            QTTS_HIP(hipMemcpy2DAsync((char*)il.p + grp, 2 * grp, m.mat(p + "mlp.up_proj.weight"), grp, grp, (size_t)c.inter / 4, hipMemcpyDeviceToDevice, st));
+            w.gate_up_il = pack_matrix(m, il.p, 2 * (int64_t)c.inter, c.hidden);
+            if (w.gate_up_il.packed) staging.push_back(std::move(il));
+            else m.owned.push_back(std::move(il));
+        }
+        w.qkv = pack_matrix(m, qkv.p, nq + 2 * nk, c.hidden);
+        w.gate_up = pack_matrix(m, gu.p, 2 * (int64_t)c.inter, c.hidden);
+        if (w.qkv.packed) staging.push_back(std::move(qkv));
+        else m.owned.push_back(std::move(qkv));
+        if (w.gate_up.packed) staging.push_back(std::move(gu));
+        else m.owned.push_back(std::move(gu));
+        w.o = pack_raw(m, p + "self_attn.o_proj.weight", release);
+        w.down = pack_raw(m, p + "mlp.down_proj.weight", release);
         if (qk_norm) {
             w.q_norm = m.f32(p + "self_attn.q_norm.weight");
             w.k_norm = m.f32(p + "self_attn.k_norm.weight");
@@ -266,6 +307,8 @@ void build_stack(Model& m, StackW& s, const StackCfg& c, const std::string& pref
         }
     }
     QTTS_HIP(hipStreamSynchronize(st));
+    staging.clear();
+    for (const std::string& k : release) m.raw.erase(k);
     // the separate q/k/v and gate/up copies are no longer needed
     for (int l = 0; l < c.layers; ++l) {
         const std::string p = prefix + "layers." + std::to_string(l) + ".";
@@ -280,8 +323,8 @@ void Model::finalize() {
     QTTS_HIP(hipSetDevice(ctx->device));
     const bool have_talker = has("talker.model.norm.weight");
     if (have_talker) {
-        build_stack(*this, talker, cfg.talker, "talker.model.", true, false);
-        build_stack(*this, cp, cfg.cp, "talker.code_predictor.model.", true, false);
+        build_stack(*this, talker, cfg.talker, "talker.model.", true, false, true);
+        build_stack(*this, cp, cfg.cp, "talker.code_predictor.model.", true, false, true);
         const int H = cfg.talker.hidden, Ht = cfg.text_hidden, Hc = cfg.cp.hidden, G = cfg.groups;
         expect_shape(get("talker.model.codec_embedding.weight"), "talker.model.codec_embedding.weight", {cfg.vocab, H});
         expect_shape(get("talker.model.text_embedding.weight"), "talker.model.text_embedding.weight", {cfg.text_vocab, Ht});
@@ -290,9 +333,10 @@ void Model::finalize() {
         expect_shape(get("talker.text_projection.linear_fc2.weight"), "talker.text_projection.linear_fc2.weight", {H, Ht});
         codec_emb = mat("talker.model.codec_embedding.weight");
         text_emb = mat("talker.model.text_embedding.weight");
-        codec_head = mat("talker.codec_head.weight");
-        fc1 = mat("talker.text_projection.linear_fc1.weight");
-        fc2 = mat("talker.text_projection.linear_fc2.weight");
+        std::vector<std::string> release;
+        codec_head = pack_raw(*this, "talker.codec_head.weight", release);
+        fc1 = pack_raw(*this, "talker.text_projection.linear_fc1.weight", release);
+        fc2 = pack_raw(*this, "talker.text_projection.linear_fc2.weight", release);
         fc1_b = f32("talker.text_projection.linear_fc1.bias");
         fc2_b = f32("talker.text_projection.linear_fc2.bias");
         for (int j = 0; j < G - 1; ++j) {
@@ -301,19 +345,21 @@ void Model::finalize() {
             expect_shape(get(e), e, {cfg.cp_vocab, H});
             expect_shape(get(h), h, {cfg.cp_vocab, Hc});
             cp_emb.push_back(mat(e));
-            cp_head.push_back(mat(h));
+            cp_head.push_back(pack_raw(*this, h, release));
         }
         cp_emb_ptrs.alloc(cp_emb.size() * sizeof(void*));
         QTTS_HIP(hipMemcpy(cp_emb_ptrs.p, cp_emb.data(), cp_emb.size() * sizeof(void*), hipMemcpyHostToDevice));
         if (Hc != H) {  // code_predictor.rs:218-226
             expect_shape(get("talker.code_predictor.small_to_mtp_projection.weight"), "small_to_mtp_projection.weight", {Hc, H});
-            proj = mat("talker.code_predictor.small_to_mtp_projection.weight");
+            proj = pack_raw(*this, "talker.code_predictor.small_to_mtp_projection.weight", release);
             proj_b = f32("talker.code_predictor.small_to_mtp_projection.bias");
         }
         QTTS_CHECK(cfg.vocab <= 4096 && cfg.cp_vocab <= 4096, ERR_SHAPE, "vocabulary exceeds the sampler's LDS staging (4096)");
         QTTS_CHECK(cfg.talker.hidden % 64 == 0 && cfg.cp.hidden % 64 == 0 && cfg.text_hidden % 64 == 0 &&
                        cfg.talker.inter % 64 == 0 && cfg.cp.inter % 64 == 0,
                    ERR_SHAPE, "hidden / intermediate sizes must be multiples of 64");
+        QTTS_HIP(hipStreamSynchronize(ctx->stream));
+        for (const std::string& k : release) raw.erase(k);
         ensure_rope(talker, 1024);
         ensure_rope(cp, 64);
     }

@@ -100,7 +100,8 @@ struct CodecCfg {  // audio/decoder/config.rs
 };
 
 struct LayerW {
-    const void *qkv = nullptr, *o = nullptr, *gate_up = nullptr, *down = nullptr;  // model dtype
+    WMat qkv, o, gate_up, down;  // model dtype
+    WMat gate_up_il;  // gate|up rows interleaved in groups of four (SwiGLU inside the GEMM), fused decode stacks only
     const float *qkv_bias = nullptr, *o_bias = nullptr, *q_norm = nullptr, *k_norm = nullptr, *ln1 = nullptr, *ln2 = nullptr;
     const float *ls_attn = nullptr, *ls_mlp = nullptr;  // LayerScale (codec transformer only)
 };
@@ -128,9 +129,11 @@ struct Model {
     std::map<std::string, Tensor> raw;     // as loaded, by HF key
     std::vector<DevBuf> owned;             // fused / derived tensors
     StackW talker, cp;
-    const void *codec_emb = nullptr, *text_emb = nullptr, *codec_head = nullptr, *fc1 = nullptr, *fc2 = nullptr, *proj = nullptr;
+    const void *codec_emb = nullptr, *text_emb = nullptr;
+    WMat codec_head, fc1, fc2, proj;
     const float *fc1_b = nullptr, *fc2_b = nullptr, *proj_b = nullptr;
-    std::vector<const void*> cp_emb, cp_head;
+    std::vector<const void*> cp_emb;
+    std::vector<WMat> cp_head;
     DevBuf cp_emb_ptrs;                    // device array of G-1 table pointers
     std::shared_ptr<GenState> gen;
     std::shared_ptr<CodecState> codec_state;
@@ -152,7 +155,11 @@ struct Model {
 };
 
 // Fuses q|k|v and gate|up of every layer under `prefix` and fills the per-layer weight table.
-void build_stack(Model& m, StackW& s, const StackCfg& c, const std::string& prefix, bool qk_norm, bool layer_scale);
+void build_stack(Model& m, StackW& s, const StackCfg& c, const std::string& prefix, bool qk_norm, bool layer_scale,
+                 bool fused_layout = false);
+// [N][K] matrix of the model dtype -> fragment order in a buffer the model owns (asynchronous on the model's stream; `src`
+// must stay alive until the stream has been synchronised).  Row-major WMat of `src` itself when the shape does not tile.
+WMat pack_matrix(Model& m, const void* src, int64_t N, int64_t K);
 
 // cos/sin tables on the host exactly as the reference computes them
 void rope_table_default(int d, double theta, int max_pos, std::vector<float>& cos, std::vector<float>& sin);  // rope/core.rs:150-160

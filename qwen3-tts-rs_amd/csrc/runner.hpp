@@ -15,6 +15,9 @@ struct Workspace {
     // bf16 runs: xn, attn and act carry a remainder plane this many elements behind the first (0 = single plane),
     // so that the GEMMs see their activations to about 16 significant bits; the buffers are then allocated twice as large
     long lo_xn = 0, lo_attn = 0, lo_act = 0;
+    // fused decode stacks: per-row partial sums of squares of the residual stream, two generations, [tiles][ss_ld]
+    DevBuf ssA, ssB;
+    long ss_ld = 0;
     // allocates the three GEMM-input buffers for `rows` rows of `wx`, `wq`, `wa` elements (split when `split`)
     void alloc_inputs(size_t rows, size_t wx, size_t wq, size_t wa, size_t es, bool split) {
         const size_t f = split ? 2 : 1;
@@ -103,7 +106,7 @@ struct Runner {
     }
     long kstride(int M, int N) const { return (long)gemm_pad_rows(M) * N; }
 
-    void gemm(const void* W, const void* X, int M, int N, int K, int KS, int ldx, long x_lo = 0) {
+    void gemm(WMat W, const void* X, int M, int N, int K, int KS, int ldx, long x_lo = 0) {
         const bool rows = M >= rows_kernel_min_m() && N % 64 == 0;
         const bool time = timer && timer->enabled && timer->used + 2 <= 400000;
         if (time) {
@@ -136,10 +139,18 @@ struct Runner {
         const StackCfg& c = s.cfg;
         const LayerW& w = s.layers[(size_t)l];
         const int nq = c.nh * c.d, nqkv = (c.nh + 2 * c.nkv) * c.d;
-        int ks = ks_for(M, nqkv, c.hidden);
-        gemm(w.qkv, g.xn.p, M, nqkv, c.hidden, ks, c.hidden, lo_xn);
+        // decode steps of bf16 stacks: q|k|v and gate|up own finished outputs (no split-K slabs; SwiGLU inside the GEMM)
+        const bool fk = decode && full_k_usable(s, M);
+        int ks = fk ? 1 : ks_for(M, nqkv, c.hidden);
+        if (fk) {
+            FusedEpi e{};
+            e.mode = FUSED_PLAIN; e.bias = w.qkv_bias; e.out_f32 = g.part.as<float>(); e.ld_out = nqkv;
+            timed(M, nqkv, c.hidden, [&] { wide_gemm(w.qkv, g.xn.p, c.hidden, lo_xn, M, nqkv, c.hidden, e); });
+        } else {
+            gemm(w.qkv, g.xn.p, M, nqkv, c.hidden, ks, c.hidden, lo_xn);
+        }
         QkvPostArgs qa{};
-        qa.part = g.part.as<float>(); qa.KS = ks; qa.ks_stride = kstride(M, nqkv); qa.bias = w.qkv_bias;
+        qa.part = g.part.as<float>(); qa.KS = ks; qa.ks_stride = kstride(M, nqkv); qa.bias = fk ? nullptr : w.qkv_bias;
         qa.q_norm = w.q_norm; qa.k_norm = w.k_norm; qa.eps = c.eps; qa.cos = s.cos.as<float>(); qa.sin = s.sin.as<float>();
         qa.rope_mode = 0; qa.toks = toks; qa.M = M; qa.nh = c.nh; qa.nkv = c.nkv; qa.d = c.d; qa.layer = kv_layer;
         qa.q_out = g.q.as<float>();
@@ -153,13 +164,115 @@ struct Runner {
         gemm(w.o, g.attn.p, M, c.hidden, nq, ks, nq, lo_attn);
         launch_resid_norm(st, dt, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), w.o_bias, w.ls_attn, w.ln2, c.eps,
                           g.x.as<float>(), g.xn.p, nullptr, M, c.hidden, lo_xn);
-        ks = ks_for(M, 2 * c.inter, c.hidden);
-        gemm(w.gate_up, g.xn.p, M, 2 * c.inter, c.hidden, ks, c.hidden, lo_xn);
-        launch_swiglu(st, dt, g.part.as<float>(), ks, kstride(M, 2 * c.inter), g.act.p, M, c.inter, lo_act);
+        if (fk) {
+            FusedEpi e{};
+            e.mode = FUSED_SWIGLU; e.act = g.act.p; e.act_lo = lo_act;
+            timed(M, 2 * c.inter, c.hidden, [&] { wide_gemm(w.gate_up_il, g.xn.p, c.hidden, lo_xn, M, 2 * c.inter, c.hidden, e); });
+        } else {
+            ks = ks_for(M, 2 * c.inter, c.hidden);
+            gemm(w.gate_up, g.xn.p, M, 2 * c.inter, c.hidden, ks, c.hidden, lo_xn);
+            launch_swiglu(st, dt, g.part.as<float>(), ks, kstride(M, 2 * c.inter), g.act.p, M, c.inter, lo_act);
+        }
         ks = ks_for(M, c.hidden, c.inter);
         gemm(w.down, g.act.p, M, c.hidden, c.inter, ks, c.inter, lo_act);
         launch_resid_norm(st, dt, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), nullptr, w.ls_mlp, next_norm, c.eps,
                           g.x.as<float>(), xn_out, xn_f32_out, M, c.hidden, xn_out_lo);
+    }
+
+    // q|k|v and gate|up of this stack can go through the full-K kernel for M tokens (QTTS_FULL_K=0: never)
+    bool full_k_usable(const StackW& s, int M) const {
+        static const bool off = getenv("QTTS_FULL_K") && atoi(getenv("QTTS_FULL_K")) == 0;
+        const StackCfg& c = s.cfg;
+        if (off || dt != BF16 || M > 512 || s.layers.empty() || !s.layers[0].gate_up_il) return false;
+        return full_k_fits(c.hidden, lo_xn != 0) && ((c.nh + 2 * c.nkv) * c.d) % 64 == 0 && (2 * c.inter) % 64 == 0;
+    }
+
+    // finished-output GEMM with epilogue: K walked in phases inside the block at 64-row multiples, whole-K tile otherwise
+    void wide_gemm(WMat W, const void* X, int ldx, long x_lo, int M, int N, int K, const FusedEpi& e) {
+        if (gemm_stream_preferred(M, N, K, x_lo != 0)) launch_gemm_stream(st, W, X, ldx, x_lo, M, N, K, e);
+        else launch_gemm_full_k(st, W, X, ldx, x_lo, M, N, K, e);
+    }
+
+    // ---- fused decode layers (k_gemm_fused.hip): the residual stream is (x f32, xn = T(x * next norm weight), ssA partials)
+    template <typename F>
+    void timed(int M, int N, int K, F&& launch) {
+        const bool time = timer && timer->enabled && timer->used + 2 <= 400000;
+        if (time) {
+            while (timer->ev.size() < timer->used + 2) {
+                hipEvent_t ev;
+                QTTS_HIP(hipEventCreate(&ev));
+                timer->ev.push_back(ev);
+            }
+            QTTS_HIP(hipEventRecord(timer->ev[timer->used], st));
+        }
+        launch();
+        if (time) {
+            QTTS_HIP(hipEventRecord(timer->ev[timer->used + 1], st));
+            timer->used += 2;
+            timer->bytes += (double)N * K * es;
+            timer->shape.push_back(M);
+            timer->shape.push_back(N);
+            timer->shape.push_back(K);
+        }
+    }
+    // x = [resid +] X W^T + bias ; xn = T(x * nw) ; partials -> ss_out.  Returns the number of partial tiles.
+    int k_split_resid(WMat W, const void* X, long x_lo, int M, int N, int K, const float* bias, bool resid, const float* nw, float* ss_out) {
+        FusedEpi e{};
+        e.mode = FUSED_RESID; e.ss_ld = g.ss_ld; e.bias = bias; e.resid = resid ? g.x.as<float>() : nullptr; e.x_out = g.x.as<float>();
+        e.xb_out = g.xn.p; e.xb_lo = lo_xn; e.nw = nw; e.ss_out = ss_out;
+        timed(M, N, K, [&] { launch_gemm_k_split(st, W, X, K, x_lo, M, N, K, e); });
+        return fused_resid_tiles(N);
+    }
+    static bool stack_fusable(const Model& m, const StackW& s) {
+        static const bool off = getenv("QTTS_FUSED_STACK") && atoi(getenv("QTTS_FUSED_STACK")) == 0;
+        if (off || !fused_gemm_supported(m.dtype, s.cfg.hidden) || s.layers.empty()) return false;
+        const StackCfg& c = s.cfg;
+        const int nqkv = (c.nh + 2 * c.nkv) * c.d;
+        for (const LayerW& w : s.layers)
+            if (!w.gate_up_il || w.ls_attn || w.ls_mlp) return false;
+        return nqkv % 64 == 0 && (2 * c.inter) % 64 == 0 && c.hidden % 16 == 0 && (c.nh * c.d) % 64 == 0 && c.inter % 64 == 0;
+    }
+    // One decoder layer, five launches.  In: x, xn = T(x * ln1), ssA (nt_in tiles).  Out: x, xn = T(x * next_norm), ssA.
+    int layer_fused(const StackW& s, int l, int M, const Tok* toks, const KVView& kv, int kv_layer, const float* next_norm, int nt_in, bool decode) {
+        const StackCfg& c = s.cfg;
+        const LayerW& w = s.layers[(size_t)l];
+        const int nq = c.nh * c.d, nqkv = (c.nh + 2 * c.nkv) * c.d;
+        QTTS_CHECK(lo_xn == 0, ERR_STATE, "fused decode layers take single-plane layer inputs");
+        {
+            FusedEpi e{};
+            e.mode = FUSED_PLAIN; e.ss_in = g.ssA.as<float>(); e.ss_ld = g.ss_ld; e.ntiles_in = nt_in; e.H_in = c.hidden; e.eps = c.eps;
+            e.bias = w.qkv_bias; e.out_f32 = g.part.as<float>(); e.ld_out = nqkv;
+            timed(M, nqkv, c.hidden, [&] { wide_gemm(w.qkv, g.xn.p, c.hidden, 0, M, nqkv, c.hidden, e); });
+        }
+        QkvPostArgs qa{};
+        qa.part = g.part.as<float>(); qa.KS = 1; qa.ks_stride = 0; qa.bias = nullptr;
+        qa.q_norm = w.q_norm; qa.k_norm = w.k_norm; qa.eps = c.eps; qa.cos = s.cos.as<float>(); qa.sin = s.sin.as<float>();
+        qa.rope_mode = 0; qa.toks = toks; qa.M = M; qa.nh = c.nh; qa.nkv = c.nkv; qa.d = c.d; qa.layer = kv_layer;
+        qa.q_out = g.q.as<float>();
+        const float scale = (float)std::pow((double)c.d, -0.5);
+        if (decode) {
+            launch_attention_decode(st, dt, qa, kv, scale, g.attn.p, lo_attn);
+        } else {
+            launch_qkv_post(st, dt, qa, kv);
+            launch_attention(st, dt, g.q.as<float>(), toks, kv, kv_layer, M, c.nh, scale, g.attn.p, lo_attn);
+        }
+        const int nt_b = k_split_resid(w.o, g.attn.p, lo_attn, M, c.hidden, nq, w.o_bias, true, w.ln2, g.ssB.as<float>());
+        {
+            FusedEpi e{};
+            e.mode = FUSED_SWIGLU; e.ss_in = g.ssB.as<float>(); e.ss_ld = g.ss_ld; e.ntiles_in = nt_b; e.H_in = c.hidden; e.eps = c.eps;
+            e.act = g.act.p; e.act_lo = lo_act;
+            timed(M, 2 * c.inter, c.hidden, [&] { wide_gemm(w.gate_up_il, g.xn.p, c.hidden, 0, M, 2 * c.inter, c.hidden, e); });
+        }
+        return k_split_resid(w.down, g.act.p, lo_act, M, c.hidden, c.inter, nullptr, true, next_norm, g.ssA.as<float>());
+    }
+    // whole stack; afterwards xn = T(x * final_norm) and ssA holds the returned number of tiles
+    int stack_fused(const StackW& s, int M, const Tok* toks, const KVView& kv, int nt_in, bool decode) {
+        int nt = nt_in;
+        for (int l = 0; l < s.cfg.layers; ++l) {
+            const bool last = l + 1 == s.cfg.layers;
+            nt = layer_fused(s, l, M, toks, kv, l, last ? s.final_norm : s.layers[(size_t)l + 1].ln1, nt, decode);
+        }
+        return nt;
     }
 
     // kv_per_layer: the KV view holds every layer (decode caches); otherwise one layer's worth is reused
