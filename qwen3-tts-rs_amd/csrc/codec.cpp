@@ -285,7 +285,7 @@ struct Decoder {
             QTTS_HIP(hipEventCreate(&pr.b));
             QTTS_HIP(hipEventRecord(pr.a, st));
         }
-        launch_gemm_rows_epi(st, dt, pend.g->w.p, pend.X, pend.g->K, pend.ldx, pend.g->taps, (long)pend.g->dil * pend.ldx, e, pend.x_lo);
+        launch_gemm_rows_epi(st, dt, pend.g->wm(), pend.X, pend.g->K, pend.ldx, pend.g->taps, (long)pend.g->dil * pend.ldx, e, pend.x_lo);
         if (profiling) {
             QTTS_HIP(hipEventRecord(pr.b, st));
             prof.push_back(pr);
@@ -450,13 +450,13 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         Runner run(m, s.ws, nullptr);
         // input_proj (+bias) starts the residual stream
         int ks = run.ks_for(M, Hd, s.latP);
-        run.gemm(s.in_proj.w.p, s.Bf.p, M, Hd, s.latP, ks, s.latP, lo);
+        run.gemm(s.in_proj.wm(), s.Bf.p, M, Hd, s.latP, ks, s.latP, lo);
         launch_resid_norm(st, dt, nullptr, s.ws.part.as<float>(), ks, run.kstride(M, Hd), s.in_proj.bias.as<float>(), nullptr,
                           s.xf.layers[0].ln1, c.eps, s.ws.x.as<float>(), s.ws.xn.p, nullptr, M, Hd, s.ws.lo_xn);
         run.stack(s.xf, M, s.toks.as<Tok>(), kv, s.ws.xn.p, nullptr, sc != nullptr, false, s.ws.lo_xn);
         // output_proj (+bias) -> strips without padding (the next op is a kernel == stride transposed conv)
         ks = run.ks_for(M, s.latP, Hd);
-        run.gemm(s.out_proj.w.p, s.ws.xn.p, M, s.latP, Hd, ks, Hd, s.ws.lo_xn);
+        run.gemm(s.out_proj.wm(), s.ws.xn.p, M, s.latP, Hd, ks, Hd, s.ws.lo_xn);
         const float* acc = s.ws.part.as<float>();
         if (ks != 1) {  // fold the split-K slabs so that the conv epilogue sees one [M][N] matrix
             launch_bias_act(st, s.ws.part.as<float>(), ks, run.kstride(M, s.latP), nullptr, 0, s.acc.p, F32, M, s.latP);
@@ -575,7 +575,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
                     QTTS_HIP(hipEventCreate(&pr.b));
                     QTTS_HIP(hipEventRecord(pr.a, st));
                 }
-                const bool ok = launch_conv_unit(st, dt, un.c1.w.p, un.c2.w.p, (const char*)in->p + (size_t)(Pn - 6 * un.c1.dil) * CPo * es, CPo,
+                const bool ok = launch_conv_unit(st, dt, un.c1.wm(), un.c2.wm(), (const char*)in->p + (size_t)(Pn - 6 * un.c1.dil) * CPo * es, CPo,
                                                  un.c1.taps, un.c1.dil, un.c1.bias.as<float>(), un.a2.a.as<float>(), un.a2.den.as<float>(), e);
                 QTTS_CHECK(ok, ERR_STATE, "codec decode: fused residual unit refused a shape it reported as supported");
                 if (profiling) {

@@ -150,6 +150,29 @@ __device__ __forceinline__ int unit_src_piece(int lane, int h2) { return (lane &
 // 16-byte LDS slot (0..127 within the unit's 2 KiB) of piece h of MFMA lane (r, g)
 __device__ __forceinline__ int unit_slot(int r, int g, int h) { return r * 8 + ((2 * g + h) ^ unit_swz(r)); }
 
+// This lane's fragment of the 16-row weight tile that starts at row n0 (a multiple of 16) of W[N][K]: the piece pair of chunk c
+// (128 bytes of a row) is at p + c * cs and p + c * cs + hs elements - in a row-major matrix, or in one re-laid into fragment
+// order (pk != 0; layout: kernels.hpp WMat).
+template <typename T>
+struct WFragPtr {
+    const T* p;
+    int cs, hs;
+    __device__ __forceinline__ WFragPtr() : p(nullptr), cs(0), hs(0) {}
+    __device__ __forceinline__ WFragPtr(const T* W, int n0, int K, int lane, int pk) {
+        constexpr int HALF = 16 / (int)sizeof(T), CHUNK = 8 * HALF, EPL = 2 * HALF;
+        if (pk) {
+            cs = 128 * HALF;
+            hs = 64 * HALF;
+            p = W + (size_t)(n0 >> 4) * (K / CHUNK) * cs + lane * HALF;
+        } else {
+            cs = CHUNK;
+            hs = HALF;
+            p = W + (size_t)(n0 + (lane & 15)) * K + (lane >> 4) * EPL;
+        }
+    }
+    __device__ __forceinline__ const T* chunk(int c) const { return p + (size_t)c * cs; }
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -236,7 +236,7 @@ void run_encode_audio(Model& m, const float* audio, const int* n_samples, int B,
         auto zero = [&](DevBuf& d, long rows, int C) { QTTS_HIP(hipMemsetAsync(d.p, 0, (size_t)(rows + ENC_SLACK) * C * es, st)); };
         auto conv = [&](const GemmW& g, const void* X, int ldx, long M, ConvEpi e) {
             e.M = M; e.N = g.N; e.r = 1; e.Cout = g.CoutP; e.bias = g.bias.p ? g.bias.as<float>() : nullptr;
-            launch_gemm_rows_epi(st, dt, g.w.p, X, g.K, ldx, g.taps, (long)g.dil * ldx, e);
+            launch_gemm_rows_epi(st, dt, g.wm(), X, g.K, ldx, g.taps, (long)g.dil * ldx, e);
         };
         auto at = [&](const DevBuf& d, long row, int ld) { return (const char*)d.p + (size_t)row * ld * es; };
 
@@ -358,7 +358,7 @@ void run_encode_audio(Model& m, const float* audio, const int* n_samples, int B,
         int q = 0;
         for (int gi = 0; gi < 2 && q < Q; ++gi) {
             const EncoderState::Group& g = s.group[gi];
-            launch_gemm_rows(st, dt, g.in_proj.w.p, s.X.p, s.acc.as<float>(), Mq, ENC_CD, ENC_DIM, ENC_DIM, 1, 0);
+            launch_gemm_rows(st, dt, g.in_proj.wm(), s.X.p, s.acc.as<float>(), Mq, ENC_CD, ENC_DIM, ENC_DIM, 1, 0);
             QTTS_HIP(hipMemcpyAsync(s.res.p, s.acc.p, (size_t)Mq * ENC_CD * 4, hipMemcpyDeviceToDevice, st));
             launch_cast_rows(st, s.acc.as<float>(), s.res_t.p, dt, Mq * ENC_CD);
             for (size_t l = 0; l < g.layers.size() && q < Q; ++l, ++q) {

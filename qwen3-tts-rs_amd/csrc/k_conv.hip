@@ -24,9 +24,9 @@ template <>
 struct CFrag<bf16_t> {
     static constexpr int CHUNK = 64, EPL = 16;
     bf16x8_t v[2];
-    __device__ __forceinline__ void load(const bf16_t* p) {
+    __device__ __forceinline__ void load(const bf16_t* p, int hs) {  // hs: elements between the lane's two 16-byte pieces
         v[0] = *reinterpret_cast<const bf16x8_t*>(p);
-        v[1] = *reinterpret_cast<const bf16x8_t*>(p + 8);
+        v[1] = *reinterpret_cast<const bf16x8_t*>(p + hs);
     }
     static __device__ __forceinline__ f32x4_t mma(const CFrag& a, const CFrag& b, f32x4_t c) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v[0], b.v[0], c, 0, 0, 0);
@@ -38,9 +38,9 @@ template <>
 struct CFrag<float> {
     static constexpr int CHUNK = 32, EPL = 8;
     float v[8];
-    __device__ __forceinline__ void load(const float* p) {
+    __device__ __forceinline__ void load(const float* p, int hs) {
         const float4 a = *reinterpret_cast<const float4*>(p);
-        const float4 b = *reinterpret_cast<const float4*>(p + 4);
+        const float4 b = *reinterpret_cast<const float4*>(p + hs);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     }
     static __device__ __forceinline__ f32x4_t mma(const CFrag& a, const CFrag& b, f32x4_t c) {
@@ -149,7 +149,7 @@ __device__ __forceinline__ void epi_rows_finish(const ConvEpi& e, const EpiCols&
 }
 
 template <typename T, int MT, int NT>
-__global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W, const T* __restrict__ X, int K, int C, int taps, int dil,
+__global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W, int wpk, const T* __restrict__ X, int K, int C, int taps, int dil,
                                                         ConvEpi e) {
     using F = CFrag<T>;
     extern __shared__ uint4 tile[];
@@ -172,14 +172,14 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     constexpr int PF = MT * NT >= 12 ? 2 : 4;  // weight chunks in flight per wave (register budget)
     F a[PF][NT];
-    const T* wrow[NT];
+    WFragPtr<T> wrow[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) wrow[j] = W + (size_t)(nb + (4 * j + wave) * 16 + r) * K + g * F::EPL;
+    for (int j = 0; j < NT; ++j) wrow[j] = WFragPtr<T>(W, nb + (4 * j + wave) * 16, K, lane, wpk);
 #pragma unroll
     for (int s = 0; s < PF - 1; ++s)
         if (s < nC) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) a[s][j].load(wrow[j] + (size_t)s * F::CHUNK);
+            for (int j = 0; j < NT; ++j) a[s][j].load(wrow[j].chunk(s), wrow[j].hs);
         }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's part of the tile has landed before it signals the barrier
     __syncthreads();
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
             const int q = q0 + s;
             if (q + PF - 1 < nC) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) a[(s + PF - 1) % PF][j].load(wrow[j] + (size_t)(q + PF - 1) * F::CHUNK);
+                for (int j = 0; j < NT; ++j) a[(s + PF - 1) % PF][j].load(wrow[j].chunk(q + PF - 1), wrow[j].hs);
             }
             if (q < nC) {
                 const int tap = q / cpt, c = q - tap * cpt;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
 // what bounds it.  The input channels are walked in phases of `cph` channels so that the tile of 256 rows + halo stays in LDS
 // whatever the layer's width; the weight stream is prefetched across phase boundaries.
 template <typename T, int MT, int NT, int WN>
-__global__ __launch_bounds__(256) void conv_tile_kernel(const T* __restrict__ W, const T* __restrict__ X, int K, int C, int taps, int dil,
+__global__ __launch_bounds__(256) void conv_tile_kernel(const T* __restrict__ W, int wpk, const T* __restrict__ X, int K, int C, int taps, int dil,
                                                         int cph, ConvEpi e) {
     using F = CFrag<T>;
     extern __shared__ uint4 tile[];
@@ -269,19 +269,19 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const T* __restrict__ W,
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     constexpr int PF = 2;  // weight chunks in flight per wave
     F a[PF][NT];
-    const T* wrow[NT];
+    WFragPtr<T> wrow[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) wrow[j] = W + (size_t)(nb + (j * WN + wn) * 16 + r) * K + g * F::EPL;
-    // chunk q of the K walk: phase ph, tap, chunk c inside the phase's channels
+    for (int j = 0; j < NT; ++j) wrow[j] = WFragPtr<T>(W, nb + (j * WN + wn) * 16, K, lane, wpk);
+    // chunk q of the K walk (phase ph, tap, chunk c inside the phase's channels): its chunk index in a weight row
     auto woff = [&](int q) {
         const int ph = q / per_phase, rem = q - ph * per_phase;
         const int tap = rem / cpp, c = rem - tap * cpp;
-        return (size_t)tap * C + (size_t)ph * cph + (size_t)c * F::CHUNK;
+        return (tap * C + ph * cph) / F::CHUNK + c;
     };
     {
-        const size_t o = woff(0);
+        const int o = woff(0);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) a[0][j].load(wrow[j] + o);
+        for (int j = 0; j < NT; ++j) a[0][j].load(wrow[j].chunk(o), wrow[j].hs);
     }
     for (int q0 = 0; q0 < nC; q0 += PF) {
 #pragma unroll
@@ -296,9 +296,9 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const T* __restrict__ W,
                 __syncthreads();
             }
             if (q + 1 < nC) {
-                const size_t o = woff(q + 1);
+                const int o = woff(q + 1);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) a[(s + 1) % PF][j].load(wrow[j] + o);
+                for (int j = 0; j < NT; ++j) a[(s + 1) % PF][j].load(wrow[j].chunk(o), wrow[j].hs);
             }
             const int tap = rem / cpp, c = rem - tap * cpp;
             const int vb = (c * F::CHUNK + g * F::EPL) / VPE;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const T* __restrict__ W,
 }
 
 template <typename T, int MT, int NT, int WN>
-void launch_tile(hipStream_t st, const T* W, const T* X, int K, int C, int taps, int dil, int cph, const ConvEpi& e) {
+void launch_tile(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, int taps, int dil, int cph, const ConvEpi& e) {
     constexpr int RT = 16 * MT * (4 / WN);
     constexpr int PT = NT % 2 == 0 ? 2 : 1;
     const size_t lds = (std::max((size_t)(RT + (taps - 1) * dil) * cph * sizeof(T), (size_t)RT * (16 * WN * PT + 4) * 4) + 1023) / 1024 * 1024;
@@ -354,13 +354,13 @@ void launch_tile(hipStream_t st, const T* W, const T* X, int K, int C, int taps,
     auto* fn = conv_tile_kernel<T, MT, NT, WN>;
     // the same ceiling from every caller: streams of several host threads launch this kernel with different tile sizes
     QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_CEILING));
-    hipLaunchKernelGGL(fn, dim3(e.N / (16 * NT * WN), (unsigned)gy), dim3(256), lds, st, W, X, K, C, taps, dil, cph, e);
+    hipLaunchKernelGGL(fn, dim3(e.N / (16 * NT * WN), (unsigned)gy), dim3(256), lds, st, W, wpk, X, K, C, taps, dil, cph, e);
 }
 
 // 256 x 128 or 256 x 192 tiles.  The choice depends on the layer only, never on the number of rows: a row's result must not
 // depend on what else is in the batch (the two kernels walk K in different orders).
 template <typename T>
-bool try_tile(hipStream_t st, const T* W, const T* X, int K, int C, int taps, int dil, const ConvEpi& e) {
+bool try_tile(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, int taps, int dil, const ConvEpi& e) {
     static const bool off = getenv("QTTS_CONV_TILE2") && atoi(getenv("QTTS_CONV_TILE2")) == 0;
     static const long min_rows = getenv("QTTS_CONV_TILE2_ROWS") ? atol(getenv("QTTS_CONV_TILE2_ROWS")) : 1;
     static const long min_k = getenv("QTTS_CONV_TILE2_K") ? atol(getenv("QTTS_CONV_TILE2_K")) : 5000;
@@ -378,8 +378,8 @@ bool try_tile(hipStream_t st, const T* W, const T* X, int K, int C, int taps, in
     for (int c = C; c >= 64; c -= 64)
         if (C % c == 0 && (size_t)(256 + halo) * c * sizeof(T) <= (size_t)96 * 1024) { cph = c; break; }
     if (cph == 0) return false;
-    if (e.N % 128 == 0) launch_tile<T, 8, 4, 2>(st, W, X, K, C, taps, dil, cph, e);
-    else if (e.N % 192 == 0) launch_tile<T, 8, 6, 2>(st, W, X, K, C, taps, dil, cph, e);
+    if (e.N % 128 == 0) launch_tile<T, 8, 4, 2>(st, W, wpk, X, K, C, taps, dil, cph, e);
+    else if (e.N % 192 == 0) launch_tile<T, 8, 6, 2>(st, W, wpk, X, K, C, taps, dil, cph, e);
     else return false;
     return true;
 }
@@ -391,7 +391,7 @@ bool try_tile(hipStream_t st, const T* W, const T* X, int K, int C, int taps, in
 // copy for the next layer).  The intermediate tensor never leaves the CU, and the HBM-bound tail of one block overlaps the
 // MFMA phases of the others.  A block owns all N = C output channels (NT = C / 64 column tiles per wave).
 template <typename T, int MT, int NT>
-__global__ __launch_bounds__(256) void conv_unit_kernel(const T* __restrict__ W1, const T* __restrict__ W2, const T* __restrict__ X, int taps,
+__global__ __launch_bounds__(256) void conv_unit_kernel(const T* __restrict__ W1, const T* __restrict__ W2, int wpk, const T* __restrict__ X, int taps,
                                                         int dil, const float* __restrict__ bias1, const float* __restrict__ alpha2,
                                                         const float* __restrict__ den2, ConvEpi e) {
     using F = CFrag<T>;
@@ -434,14 +434,14 @@ __global__ __launch_bounds__(256) void conv_unit_kernel(const T* __restrict__ W1
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     constexpr int PF = MT * NT >= 12 ? 2 : 4;
     F a[PF][NT];
-    const T* wrow[NT];
+    WFragPtr<T> wrow[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) wrow[j] = W1 + (size_t)((4 * j + wave) * 16 + r) * K + g * F::EPL;
+    for (int j = 0; j < NT; ++j) wrow[j] = WFragPtr<T>(W1, (4 * j + wave) * 16, K, lane, wpk);
 #pragma unroll
     for (int s = 0; s < PF - 1; ++s)
         if (s < nC) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) a[s][j].load(wrow[j] + (size_t)s * F::CHUNK);
+            for (int j = 0; j < NT; ++j) a[s][j].load(wrow[j].chunk(s), wrow[j].hs);
         }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     __syncthreads();
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void conv_unit_kernel(const T* __restrict__ W1
             const int q = q0 + s;
             if (q + PF - 1 < nC) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) a[(s + PF - 1) % PF][j].load(wrow[j] + (size_t)(q + PF - 1) * F::CHUNK);
+                for (int j = 0; j < NT; ++j) a[(s + PF - 1) % PF][j].load(wrow[j].chunk(q + PF - 1), wrow[j].hs);
             }
             if (q < nC) {
                 const int tap = q / cpt, c = q - tap * cpt;
@@ -481,7 +481,10 @@ __global__ __launch_bounds__(256) void conv_unit_kernel(const T* __restrict__ W1
 #pragma unroll
     for (int c = 0; c < cpt; ++c)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) a2[c][j].load(W2 + (size_t)((4 * j + wave) * 16 + r) * C + g * F::EPL + c * F::CHUNK);
+        for (int j = 0; j < NT; ++j) {
+            const WFragPtr<T> w2(W2, (4 * j + wave) * 16, C, lane, wpk);
+            a2[c][j].load(w2.chunk(c), w2.hs);
+        }
     // tail of the 7-tap conv: bias, SnakeBeta of the value the unfused layer would have stored, into the second tile.  A lane
     // holds four consecutive channels of one row: one 8- or 16-byte store into the swizzled row-major layout.
 #pragma unroll
@@ -541,7 +544,7 @@ __global__ __launch_bounds__(256) void conv_unit_kernel(const T* __restrict__ W1
 bool conv_unit_supported_fwd(int dtype, int C, int taps, int dil);
 
 template <typename T, int NT>
-bool launch_unit(hipStream_t st, const T* W1, const T* W2, const T* X, int taps, int dil, const float* bias1, const float* alpha2,
+bool launch_unit(hipStream_t st, const T* W1, const T* W2, int wpk, const T* X, int taps, int dil, const float* bias1, const float* alpha2,
                  const float* den2, const ConvEpi& e) {
     constexpr int MT = 4, RT = 64, C = 64 * NT, PT = NT % 2 == 0 ? 2 : 1;
     const size_t tile_b = (std::max((size_t)(RT + (taps - 1) * dil) * C * sizeof(T), (size_t)RT * (64 * PT + 4) * 4) + 1023) / 1024 * 1024;
@@ -551,32 +554,32 @@ bool launch_unit(hipStream_t st, const T* W1, const T* W2, const T* X, int taps,
     if (gx > 0x7fffffffL) return false;
     auto* fn = conv_unit_kernel<T, MT, NT>;
     QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_CEILING));
-    hipLaunchKernelGGL(fn, dim3((unsigned)gx), dim3(256), lds, st, W1, W2, X, taps, dil, bias1, alpha2, den2, e);
+    hipLaunchKernelGGL(fn, dim3((unsigned)gx), dim3(256), lds, st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e);
     return true;
 }
 
 template <typename T>
-bool try_unit(hipStream_t st, const T* W1, const T* W2, const T* X, int C, int taps, int dil, const float* bias1, const float* alpha2,
+bool try_unit(hipStream_t st, const T* W1, const T* W2, int wpk, const T* X, int C, int taps, int dil, const float* bias1, const float* alpha2,
               const float* den2, const ConvEpi& e) {
     if (e.N != C || e.r != 1 || !conv_unit_supported_fwd(sizeof(T) == 2 ? BF16 : F32, C, taps, dil)) return false;
-    if (C == 64) return launch_unit<T, 1>(st, W1, W2, X, taps, dil, bias1, alpha2, den2, e);
-    if (C == 128) return launch_unit<T, 2>(st, W1, W2, X, taps, dil, bias1, alpha2, den2, e);
-    if (C == 192) return launch_unit<T, 3>(st, W1, W2, X, taps, dil, bias1, alpha2, den2, e);
+    if (C == 64) return launch_unit<T, 1>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e);
+    if (C == 128) return launch_unit<T, 2>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e);
+    if (C == 192) return launch_unit<T, 3>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e);
     if constexpr (sizeof(T) == 2) {
-        if (C == 256) return launch_unit<T, 4>(st, W1, W2, X, taps, dil, bias1, alpha2, den2, e);
+        if (C == 256) return launch_unit<T, 4>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e);
     }
     return false;
 }
 
 template <typename T, int MT, int NT>
-void launch_halo(hipStream_t st, const T* W, const T* X, int K, int C, int taps, int dil, const ConvEpi& e, size_t lds) {
+void launch_halo(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, int taps, int dil, const ConvEpi& e, size_t lds) {
     const long RT = 16 * MT;
     const long gy = (e.M + RT - 1) / RT;
-    hipLaunchKernelGGL((conv_halo_kernel<T, MT, NT>), dim3(e.N / (64 * NT), (unsigned)gy), dim3(256), lds, st, W, X, K, C, taps, dil, e);
+    hipLaunchKernelGGL((conv_halo_kernel<T, MT, NT>), dim3(e.N / (64 * NT), (unsigned)gy), dim3(256), lds, st, W, wpk, X, K, C, taps, dil, e);
 }
 
 template <typename T>
-bool try_halo(hipStream_t st, const T* W, const T* X, int K, int C, int taps, int dil, const ConvEpi& e) {
+bool try_halo(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, int taps, int dil, const ConvEpi& e) {
     // Tile shapes (rows x columns per block): 64 x 256 when N allows (four MFMAs per LDS fragment), 128 x 128 for
     // 128-column layers with many rows (halves the weight traffic), 64 x 128, else 128 x 64 / 64 x 64.
     const size_t row_bytes = (size_t)C * sizeof(T);
@@ -597,11 +600,11 @@ bool try_halo(hipStream_t st, const T* W, const T* X, int K, int C, int taps, in
     const int rows = 16 * mt;
     const size_t lds = (std::max((rows + halo) * row_bytes, mt == 8 ? otile128 : otile64) + 1023) / 1024 * 1024;
     if ((e.M + rows - 1) / rows > 0x7fffffffL) return false;
-    if (mt == 4 && nt == 4) launch_halo<T, 4, 4>(st, W, X, K, C, taps, dil, e, lds);
-    else if (mt == 8 && nt == 2) launch_halo<T, 8, 2>(st, W, X, K, C, taps, dil, e, lds);
-    else if (mt == 4 && nt == 2) launch_halo<T, 4, 2>(st, W, X, K, C, taps, dil, e, lds);
-    else if (mt == 8) launch_halo<T, 8, 1>(st, W, X, K, C, taps, dil, e, lds);
-    else launch_halo<T, 4, 1>(st, W, X, K, C, taps, dil, e, lds);
+    if (mt == 4 && nt == 4) launch_halo<T, 4, 4>(st, W, wpk, X, K, C, taps, dil, e, lds);
+    else if (mt == 8 && nt == 2) launch_halo<T, 8, 2>(st, W, wpk, X, K, C, taps, dil, e, lds);
+    else if (mt == 4 && nt == 2) launch_halo<T, 4, 2>(st, W, wpk, X, K, C, taps, dil, e, lds);
+    else if (mt == 8) launch_halo<T, 8, 1>(st, W, wpk, X, K, C, taps, dil, e, lds);
+    else launch_halo<T, 4, 1>(st, W, wpk, X, K, C, taps, dil, e, lds);
     return true;
 }
 
@@ -609,7 +612,9 @@ bool try_halo(hipStream_t st, const T* W, const T* X, int K, int C, int taps, in
 
 // Returns false when the shape does not fit the LDS-tile kernel (the caller then uses the tap-addressed GEMM).
 // X rows must be contiguous (row stride == channels per tap) and readable for 256 rows + the halo past e.M.
-bool launch_conv_halo(hipStream_t st, int dtype, const void* W, const void* X, int K, int ldx, int taps, long tap_stride, const ConvEpi& e) {
+bool launch_conv_halo(hipStream_t st, int dtype, WMat Wm, const void* X, int K, int ldx, int taps, long tap_stride, const ConvEpi& e) {
+    const void* W = Wm.p;
+    const int wpk = Wm.packed ? 1 : 0;
     if (taps < 1 || K % taps != 0) return false;
     const int C = K / taps;
     const int chunk = dtype == BF16 ? 64 : 32;
@@ -618,11 +623,11 @@ bool launch_conv_halo(hipStream_t st, int dtype, const void* W, const void* X, i
     const long dil = taps > 1 ? tap_stride / ldx : 1;
     if (dil < 1 || dil > 64) return false;
     if (dtype == BF16) {
-        if (try_tile<bf16_t>(st, (const bf16_t*)W, (const bf16_t*)X, K, C, taps, (int)dil, e)) return true;
-        return try_halo<bf16_t>(st, (const bf16_t*)W, (const bf16_t*)X, K, C, taps, (int)dil, e);
+        if (try_tile<bf16_t>(st, (const bf16_t*)W, wpk, (const bf16_t*)X, K, C, taps, (int)dil, e)) return true;
+        return try_halo<bf16_t>(st, (const bf16_t*)W, wpk, (const bf16_t*)X, K, C, taps, (int)dil, e);
     }
-    if (try_tile<float>(st, (const float*)W, (const float*)X, K, C, taps, (int)dil, e)) return true;
-    return try_halo<float>(st, (const float*)W, (const float*)X, K, C, taps, (int)dil, e);
+    if (try_tile<float>(st, (const float*)W, wpk, (const float*)X, K, C, taps, (int)dil, e)) return true;
+    return try_halo<float>(st, (const float*)W, wpk, (const float*)X, K, C, taps, (int)dil, e);
 }
 
 // Shapes the fused residual unit covers: 64 / 128 / 192 (bf16: / 256) channels with a tile that leaves two blocks per CU.
@@ -643,11 +648,14 @@ bool conv_unit_supported_fwd(int dtype, int C, int taps, int dil) { return conv_
 // Fused residual unit: conv (taps, dilation; W1 [C][taps * C]) + bias1 + SnakeBeta(alpha2, den2), then the 1x1 conv W2 [C][C] with the
 // epilogue e (bias, f32 residual, outputs).  X as for launch_conv_halo.  False = shape not covered (the caller launches the two
 // convs one after the other).
-bool launch_conv_unit(hipStream_t st, int dtype, const void* W1, const void* W2, const void* X, int C, int taps, int dil, const float* bias1,
+bool launch_conv_unit(hipStream_t st, int dtype, WMat W1m, WMat W2m, const void* X, int C, int taps, int dil, const float* bias1,
                       const float* alpha2, const float* den2, const ConvEpi& e) {
+    const void *W1 = W1m.p, *W2 = W2m.p;
+    QTTS_CHECK(W1m.packed == W2m.packed, ERR_BAD_ARG, "conv_unit: the two weight matrices must share a layout");
+    const int wpk = W1m.packed ? 1 : 0;
     QTTS_CHECK(W1 && W2 && X && bias1 && alpha2 && den2 && e.lens && e.M >= 1 && e.S_in >= 1, ERR_BAD_ARG, "conv_unit: null argument");
-    if (dtype == BF16) return try_unit<bf16_t>(st, (const bf16_t*)W1, (const bf16_t*)W2, (const bf16_t*)X, C, taps, dil, bias1, alpha2, den2, e);
-    return try_unit<float>(st, (const float*)W1, (const float*)W2, (const float*)X, C, taps, dil, bias1, alpha2, den2, e);
+    if (dtype == BF16) return try_unit<bf16_t>(st, (const bf16_t*)W1, (const bf16_t*)W2, wpk, (const bf16_t*)X, C, taps, dil, bias1, alpha2, den2, e);
+    return try_unit<float>(st, (const float*)W1, (const float*)W2, wpk, (const float*)X, C, taps, dil, bias1, alpha2, den2, e);
 }
 
 }  // namespace qtts

@@ -230,9 +230,9 @@ void launch_gemm_rows_epi(hipStream_t st, int dtype, WMat W, const void* X, int 
 // k_conv.hip: same contract with the input tile held in LDS; false = shape not covered (use launch_gemm_rows_epi).
 // X must be readable for CONV_HALO_SLACK rows past e.M.
 constexpr long CONV_HALO_SLACK = 384;
-bool launch_conv_halo(hipStream_t st, int dtype, const void* W, const void* X, int K, int ldx, int taps, long tap_stride, const ConvEpi& e);
+bool launch_conv_halo(hipStream_t st, int dtype, WMat W, const void* X, int K, int ldx, int taps, long tap_stride, const ConvEpi& e);
 bool conv_unit_supported(int dtype, int C, int taps, int dil);
-bool launch_conv_unit(hipStream_t st, int dtype, const void* W1, const void* W2, const void* X, int C, int taps, int dil, const float* bias1,
+bool launch_conv_unit(hipStream_t st, int dtype, WMat W1, WMat W2, const void* X, int C, int taps, int dil, const float* bias1,
                       const float* alpha2, const float* den2, const ConvEpi& e);
 void launch_rvq_gather(hipStream_t st, int dtype, const float* table, const unsigned* codes, const int* rows, const int* starts,
                        const int* lens, int U, int Tc, int Q, int csize, int Dc, int T_max, long S, int P, void* out, int ld, long out_lo = 0);

@@ -212,7 +212,7 @@ void Model::ensure_rope(StackW& s, int max_pos) {
 }
 
 // GEMM weights are re-laid into MFMA fragment order once, here (kernels.hpp WMat); QTTS_PACK_WEIGHTS=0 keeps them row-major.
-static bool pack_weights_enabled() {
+bool pack_weights_enabled() {
     static const bool on = !(getenv("QTTS_PACK_WEIGHTS") && atoi(getenv("QTTS_PACK_WEIGHTS")) == 0);
     return on;
 }

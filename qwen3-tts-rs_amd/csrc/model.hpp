@@ -160,6 +160,7 @@ void build_stack(Model& m, StackW& s, const StackCfg& c, const std::string& pref
 // [N][K] matrix of the model dtype -> fragment order in a buffer the model owns (asynchronous on the model's stream; `src`
 // must stay alive until the stream has been synchronised).  Row-major WMat of `src` itself when the shape does not tile.
 WMat pack_matrix(Model& m, const void* src, int64_t N, int64_t K);
+bool pack_weights_enabled();  // QTTS_PACK_WEIGHTS=0 keeps every GEMM weight row-major
 
 // cos/sin tables on the host exactly as the reference computes them
 void rope_table_default(int d, double theta, int max_pos, std::vector<float>& cos, std::vector<float>& sin);  // rope/core.rs:150-160

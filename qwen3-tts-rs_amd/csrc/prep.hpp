@@ -4,6 +4,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -40,9 +41,41 @@ inline void upload(DevBuf& d, const std::vector<float>& v, int dtype) {
 }
 
 struct GemmW {
-    DevBuf w, bias;  // w: [N][K] model dtype; bias: [CoutP] f32 (zeros when absent)
+    DevBuf w, bias;  // w: [N][K] model dtype (in fragment order when `packed`); bias: [CoutP] f32 (zeros when absent)
+    bool packed = false;
     int N = 0, K = 0, taps = 1, dil = 1, r = 1, CinP = 0, CoutP = 0;
+    WMat wm() const { return WMat(w.p, packed); }
 };
+
+// Uploads a host [N][K] f32 matrix in the model dtype, re-laid into MFMA fragment order (kernels.hpp WMat) when the shape
+// tiles (N % 16 == 0, rows of whole 128-byte segments) and packing is enabled.
+inline void upload_matrix(GemmW& g, const std::vector<float>& v, int N, int K, int dtype) {
+    const size_t es = dtype_size(dtype);
+    const size_t row_bytes = (size_t)K * es;
+    QTTS_CHECK(v.size() == (size_t)N * K, ERR_SHAPE, "upload_matrix: size mismatch");
+    std::vector<uint8_t> rm((size_t)N * row_bytes);
+    if (dtype == F32) {
+        std::memcpy(rm.data(), v.data(), rm.size());
+    } else {
+        uint16_t* o = reinterpret_cast<uint16_t*>(rm.data());
+        for (size_t i = 0; i < v.size(); ++i) o[i] = f32_to_bf16(v[i]);
+    }
+    g.packed = pack_weights_enabled() && N % 16 == 0 && row_bytes % 128 == 0;
+    g.w.alloc(rm.size());
+    if (!g.packed) {
+        QTTS_HIP(hipMemcpy(g.w.p, rm.data(), rm.size(), hipMemcpyHostToDevice));
+        return;
+    }
+    std::vector<uint8_t> pk(rm.size());
+    const size_t ppr = row_bytes / 16, nC = ppr / 8;
+    for (size_t n = 0; n < (size_t)N; ++n)
+        for (size_t q = 0; q < ppr; ++q) {
+            const size_t c = q >> 3, pp = q & 7;
+            const size_t d = ((((n >> 4) * nC + c) * 2 + (pp & 1)) * 64) + (n & 15) + 16 * (pp >> 1);
+            std::memcpy(pk.data() + d * 16, rm.data() + (n * ppr + q) * 16, 16);
+        }
+    QTTS_HIP(hipMemcpy(g.w.p, pk.data(), pk.size(), hipMemcpyHostToDevice));
+}
 
 struct Snake {
     DevBuf a, den;  // exp(alpha), exp(beta) + 1e-9
@@ -75,7 +108,7 @@ inline void conv_weight(const Model& m, const std::string& prefix, int dil, Gemm
     for (int co = 0; co < Cout; ++co)
         for (int ci = 0; ci < Cin; ++ci)
             for (int j = 0; j < k; ++j) out[(size_t)co * g.K + (size_t)j * g.CinP + ci] = w[((size_t)co * Cin + ci) * k + j];
-    upload(g.w, out, m.dtype);
+    upload_matrix(g, out, g.N, g.K, m.dtype);
     load_bias(m, prefix + ".bias", g.CoutP, g);
 }
 
@@ -108,7 +141,7 @@ inline void convT_weight(const Model& m, const std::string& prefix, int r, GemmW
                     out[row * g.K + ci] = w[((size_t)ci * Cout + co) * k + j];
                 }
             }
-    upload(g.w, out, m.dtype);
+    upload_matrix(g, out, g.N, g.K, m.dtype);
     load_bias(m, prefix + ".bias", g.CoutP, g);
 }
 
@@ -125,7 +158,7 @@ inline void linear_weight(const Model& m, const std::string& prefix, GemmW& g) {
     std::vector<float> out((size_t)g.N * g.K, 0.f);
     for (int co = 0; co < Cout; ++co)
         for (int ci = 0; ci < Cin; ++ci) out[(size_t)co * g.K + ci] = w[(size_t)co * Cin + ci];
-    upload(g.w, out, m.dtype);
+    upload_matrix(g, out, g.N, g.K, m.dtype);
     load_bias(m, prefix + ".bias", g.CoutP, g);
 }
 

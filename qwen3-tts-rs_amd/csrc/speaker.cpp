@@ -343,7 +343,7 @@ void speaker_embed_impl(Model& m, const float* audio, const int* n_samples, int 
         ConvEpi e{};
         e.M = M; e.N = g.N; e.r = 1; e.Cout = g.CoutP; e.bias = g.bias.p ? g.bias.as<float>() : nullptr; e.bias_u = bias_u;
         e.Cvalid = Cvalid; e.act = act; e.lens = d_len; e.S_in = S; e.S_out = S; e.P_out = P; e.ld_out = ld_out; e.out = out;
-        launch_gemm_rows_epi(st, dt, g.w.p, X, g.K, ldx, g.taps, (long)g.dil * ldx, e);
+        launch_gemm_rows_epi(st, dt, g.wm(), X, g.K, ldx, g.taps, (long)g.dil * ldx, e);
     };
     auto at = [&](const DevBuf& d, long row, int ld) { return (const char*)d.p + (size_t)row * ld * es; };
 
@@ -407,7 +407,7 @@ void speaker_embed_impl(Model& m, const float* audio, const int* n_samples, int 
     s.asp_a.taps = 1;
     s.asp_a.dil = 1;
     conv(s.asp_a, at(s.mm, P, s.CmP), s.CmP, 3, s.att.p, s.CaP, s.vec2.as<float>(), (s.Ca + 3) / 4 * 4);
-    launch_gemm_rows(st, dt, s.asp_conv.w.p, at(s.att, P, s.CaP), acc, M, s.asp_conv.N, s.asp_conv.K, s.CaP, 1, 0);
+    launch_gemm_rows(st, dt, s.asp_conv.wm(), at(s.att, P, s.CaP), acc, M, s.asp_conv.N, s.asp_conv.K, s.CaP, 1, 0);
     // softmax over time of (asp.conv output + bias), read straight from the GEMM output (its rows carry no leading padding)
     launch_time_stats(st, dt, s.mm.p, s.CmP, acc, s.asp_conv.N, s.asp_conv.bias.as<float>(), d_len, U, S, P, 0, s.Cm, 2, s.vec1.as<float>());
     launch_small_fc(st, s.fc_w.as<float>(), 2 * s.Cm, s.fc_b.as<float>(), s.vec1.as<float>(), 2 * s.Cm, U, s.enc_dim, 2 * s.Cm, 0, s.emb.as<float>(),
