@@ -147,11 +147,10 @@ def main():
     import threading
     from qwen3_tts_rs_amd import SamplingConfig, synth
     P = max(1, min(args.pipeline, args.steps))
-    models = []
-    for _ in range(P):
-        m, cfg, ccfg, tmpl = build_model(args, local)
-        models.append(m)
-    m = models[0]
+    # one set of weights per GPU; every batch in flight beyond the first runs in a session of the same model (its own HIP
+    # stream, KV caches, workspaces and frame graph)
+    m, cfg, ccfg, tmpl = build_model(args, local)
+    models = [m] + [m.open_session() for _ in range(P - 1)]
     reqs = make_requests(args, tmpl, rank)
     sampling = SamplingConfig.cli_greedy() if args.greedy else SamplingConfig()
 
@@ -300,7 +299,7 @@ def main():
             "graph_launch_host_ms_per_frame": round(stats["launch_host_ms"] / frames_run, 4),
             "roofline": roofline, "roofline_gemm": gemm, "roofline_codec": codec, "cpu_baseline": cpu,
         }
-    for mod in models:
+    for mod in reversed(models):   # sessions before the model they borrow from
         mod.close()
     if world > 1:
         dist.barrier()

@@ -59,6 +59,21 @@ int qtts_model_load_tensor_device(qtts_model* m, const char* hf_key, const void*
 int qtts_model_finalize(qtts_model* m);
 void qtts_model_free(qtts_model* m);
 
+/* Decode sessions.  No counterpart in the reference (one ConditionalGeneration serves one generate call at a time).
+ * A session is a second decode stream on a finalized model: it borrows the model's weights (no copy) and owns a HIP stream,
+ * KV caches, workspaces and the captured frame graph, so several batches can be in flight on one GPU while every weight byte
+ * exists once.  The handle is a qtts_model handle: every entry point below that takes a qtts_model* (generate, codec decode
+ * and streaming decode, mel, speaker embedding, audio encoding, timing, info) accepts it and runs on the session's stream;
+ * qtts_model_load_tensor* and qtts_model_finalize fail on it.  Sessions of one model may be driven from different host
+ * threads (one thread per session); the codec decoder, speaker encoder and codec encoder keep one set of workspaces per
+ * model, so calls into each of them are serialised across sessions.  Close every session before qtts_model_free of the
+ * model it was opened on. */
+typedef qtts_model qtts_session;
+int qtts_session_open(qtts_model* m, qtts_session** out);
+void qtts_session_close(qtts_session* s);
+/* The session's hipStream_t. */
+void* qtts_session_stream(qtts_session* s);
+
 /* One utterance.  Mirrors GenerationOptions (nn/generation_options.rs) + the text ids handed to
  * ConditionalGeneration::generate (nn/generation.rs:815). */
 typedef struct {

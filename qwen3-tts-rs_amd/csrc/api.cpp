@@ -16,6 +16,7 @@ struct qtts_ctx {
 };
 struct qtts_model {
     Model m;
+    std::unique_ptr<Ctx> own_ctx;  // sessions: their own stream
 };
 
 namespace {
@@ -113,8 +114,35 @@ void qtts_model_free(qtts_model* m) {
     if (!m) return;
     (void)hipSetDevice(m->m.ctx->device);
     (void)hipDeviceSynchronize();
+    hipStream_t own = m->own_ctx ? m->own_ctx->stream : nullptr;
+    m->m.gen.reset();  // graphs and workspaces go before the stream they were captured on
+    if (own) (void)hipStreamDestroy(own);
     delete m;
 }
+
+int qtts_session_open(qtts_model* base, qtts_model** out) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(base && out, ERR_BAD_ARG, "qtts_session_open: null argument");
+    QTTS_CHECK(base->m.finalized, ERR_STATE, "qtts_session_open: the model is not finalized");
+    std::unique_ptr<qtts_model> s(new qtts_model());
+    s->own_ctx.reset(new Ctx());
+    s->own_ctx->device = base->m.ctx->device;
+    QTTS_HIP(hipSetDevice(s->own_ctx->device));
+    QTTS_HIP(hipStreamCreateWithFlags(&s->own_ctx->stream, hipStreamNonBlocking));
+    s->m.ctx = s->own_ctx.get();
+    try {
+        s->m.init_view(base->m);
+    } catch (...) {
+        (void)hipStreamDestroy(s->own_ctx->stream);
+        throw;
+    }
+    *out = s.release();
+    QTTS_API_END
+}
+
+void qtts_session_close(qtts_model* s) { qtts_model_free(s); }
+
+void* qtts_session_stream(qtts_model* s) { return s ? (void*)s->m.ctx->stream : nullptr; }
 
 int qtts_generate_ex(qtts_model* m, const qtts_request* reqs, int n, const qtts_sampling* s, int max_new_tokens,
                      qtts_codes_out* outs, const qtts_gen_debug* dbg) {

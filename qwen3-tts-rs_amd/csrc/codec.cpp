@@ -649,6 +649,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
 // Model::decode_output / TokenizerV2::{decode, chunked_decode} (model/generate.rs:29-143, audio/decoder/v2.rs:163-286).
 void run_codec_decode(Model& m, const uint32_t* codes, const int* lens, int B, int T_max, int chunk, int left_ctx, float* wav_out,
                       int64_t wav_stride, int64_t* wav_lens) {
+    std::lock_guard<std::mutex> lock(m.locks->codec);  // sessions of one model share the decoder's workspaces
     QTTS_CHECK(m.finalized && m.codec_state, ERR_STATE, "codec weights are not loaded");
     QTTS_CHECK(B >= 1 && T_max >= 1 && wav_stride >= 1, ERR_BAD_ARG, "codec decode: bad batch shape");
     QTTS_CHECK(chunk == -2 || chunk <= 0 || left_ctx >= 0, ERR_BAD_ARG, "codec decode: negative left context");
@@ -742,6 +743,7 @@ static int conv_context_frames(const CodecCfg& c) {
 }
 
 CodecStream* codec_stream_open(Model& m, int B, int max_chunk) {
+    std::lock_guard<std::mutex> lock(m.locks->codec);
     QTTS_CHECK(m.finalized && m.codec_state, ERR_STATE, "codec weights are not loaded");
     QTTS_CHECK(B >= 1 && B <= 4096 && max_chunk >= 1 && max_chunk <= 8192, ERR_BAD_ARG, "codec stream: bad batch or chunk size");
     QTTS_HIP(hipSetDevice(m.ctx->device));
@@ -774,6 +776,7 @@ void codec_stream_close(CodecStream* sc) {
 // up * n - tail for the first push, up * n afterwards; *n_samples is that count.
 void codec_stream_push(CodecStream& sc, const uint32_t* codes, int n, float* wav_out, int64_t wav_stride, int64_t* n_samples) {
     Model& m = *sc.m;
+    std::lock_guard<std::mutex> lock(m.locks->codec);
     QTTS_CHECK(m.finalized && m.codec_state, ERR_STATE, "codec weights are not loaded");
     QTTS_CHECK(n >= 1 && n <= sc.max_chunk, ERR_BAD_ARG, "codec stream: push is empty or longer than the session's max_chunk");
     QTTS_HIP(hipSetDevice(m.ctx->device));

@@ -164,6 +164,7 @@ void finalize_encoder(Model& m) {
 // TokenizerV2::encode for a batch of clips.  codes_out [B][T_cap][Q] u32, T_out[b] = frames of clip b.
 void run_encode_audio(Model& m, const float* audio, const int* n_samples, int B, int max_samples, int Q, uint32_t* codes_out, int T_cap,
                       int* T_out) {
+    std::lock_guard<std::mutex> lock(m.locks->encoder);  // sessions of one model share these workspaces
     QTTS_CHECK(m.finalized && m.enc_state, ERR_STATE, "Encoder not loaded. Load the speech tokenizer's encoder.* tensors to encode audio.");
     QTTS_CHECK(B >= 1 && max_samples >= 1 && Q >= 1 && T_cap >= 1, ERR_BAD_ARG, "encode_audio: bad batch shape");
     EncoderState& s = *m.enc_state;

@@ -318,6 +318,45 @@ void build_stack(Model& m, StackW& s, const StackCfg& c, const std::string& pref
     s.final_norm = m.f32(prefix + "norm.weight");
 }
 
+static void stack_view(const StackW& b, StackW& v) {
+    v.cfg = b.cfg;
+    v.layers = b.layers;
+    v.final_norm = b.final_norm;
+    v.max_pos = 0;  // RoPE tables are grown on demand by the stream that needs them: each stream has its own
+}
+
+void Model::init_view(const Model& base) {
+    QTTS_CHECK(base.finalized, ERR_STATE, "session: the model is not finalized");
+    QTTS_CHECK(!finalized && raw.empty(), ERR_STATE, "session: the handle already holds a model");
+    QTTS_HIP(hipSetDevice(ctx->device));
+    is_view = true;
+    locks = base.locks;
+    dtype = base.dtype;
+    cfg = base.cfg;
+    codec = base.codec;
+    stack_view(base.talker, talker);
+    stack_view(base.cp, cp);
+    codec_emb = base.codec_emb;
+    text_emb = base.text_emb;
+    codec_head = base.codec_head;
+    fc1 = base.fc1; fc2 = base.fc2; proj = base.proj;
+    fc1_b = base.fc1_b; fc2_b = base.fc2_b; proj_b = base.proj_b;
+    cp_emb = base.cp_emb;
+    cp_head = base.cp_head;
+    if (!cp_emb.empty()) {
+        cp_emb_ptrs.alloc(cp_emb.size() * sizeof(void*));
+        QTTS_HIP(hipMemcpy(cp_emb_ptrs.p, cp_emb.data(), cp_emb.size() * sizeof(void*), hipMemcpyHostToDevice));
+    }
+    codec_state = base.codec_state;
+    spk_state = base.spk_state;
+    enc_state = base.enc_state;
+    if (!talker.layers.empty()) {
+        ensure_rope(talker, 1024);
+        ensure_rope(cp, 64);
+    }
+    finalized = true;
+}
+
 void Model::finalize() {
     QTTS_CHECK(!finalized, ERR_STATE, "finalize called twice");
     QTTS_HIP(hipSetDevice(ctx->device));

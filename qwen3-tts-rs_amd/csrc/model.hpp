@@ -4,6 +4,7 @@
 #pragma once
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -120,8 +121,17 @@ struct CodecState;  // codec.cpp
 struct SpeakerState;
 struct EncoderState;  // encoder.cpp
 
+// The codec decoder, the speaker encoder and the codec encoder keep their weights and their workspaces in one state object
+// each; sessions of one model share those objects, so calls into them are serialised (a call returns only when its result is
+// on the host, so the workspaces are free again when the lock is released).
+struct SharedLocks {
+    std::mutex codec, speaker, encoder;
+};
+
 struct Model {
     Ctx* ctx = nullptr;
+    bool is_view = false;  // a session: weights borrowed from another model, which must outlive it
+    std::shared_ptr<SharedLocks> locks = std::make_shared<SharedLocks>();
     int dtype = BF16;
     ModelCfg cfg;
     CodecCfg codec;
@@ -152,6 +162,9 @@ struct Model {
     const float* f32(const std::string& key) const;
     const void* mat(const std::string& key) const;
     void ensure_rope(StackW& s, int max_pos);
+    // Makes this (empty) model a second decode stream of `base`: same weights (pointers), own RoPE tables, KV caches, workspaces
+    // and frame graph, running on this->ctx.  `base` must be finalized.
+    void init_view(const Model& base);
 };
 
 // Fuses q|k|v and gate|up of every layer under `prefix` and fills the per-layer weight table.

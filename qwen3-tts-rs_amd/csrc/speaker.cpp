@@ -197,6 +197,7 @@ Batch stage_audio(Model& m, SpeakerState& s, const float* audio, const int* n_sa
 }  // namespace
 
 void run_mel(Model& m, const float* audio, const int* n_samples, int B, int max_samples, float* mel_out, int frames_stride, int* n_frames) {
+    std::lock_guard<std::mutex> lock(m.locks->speaker);  // sessions of one model share these workspaces
     QTTS_CHECK(m.finalized && m.spk_state, ERR_STATE, "model is not finalized");
     QTTS_HIP(hipSetDevice(m.ctx->device));
     SpeakerState& s = *m.spk_state;
@@ -243,6 +244,7 @@ unsigned char* mel_scratch(int device) {
 size_t mel_scratch_bytes() { return MEL_SCRATCH_BYTES; }
 
 void run_mel_noalloc(Model& m, const float* audio, const int* n_samples, int B, int max_samples, float* mel_out, int frames_stride, int* n_frames) {
+    std::lock_guard<std::mutex> lock(m.locks->speaker);  // sessions of one model share these workspaces
     QTTS_CHECK(m.finalized && m.spk_state, ERR_STATE, "model is not finalized");
     QTTS_CHECK(B >= 1 && max_samples >= 1 && frames_stride >= 1, ERR_BAD_ARG, "mel: bad batch shape");
     QTTS_HIP(hipSetDevice(m.ctx->device));
@@ -280,12 +282,14 @@ void speaker_embed_impl(Model& m, const float* audio, const int* n_samples, int 
 }
 
 void run_speaker_embed(Model& m, const float* audio, const int* n_samples, int B, int max_samples, float* emb_out) {
+    std::lock_guard<std::mutex> lock(m.locks->speaker);  // sessions of one model share these workspaces
     speaker_embed_impl(m, audio, n_samples, max_samples, nullptr, nullptr, 0, B, emb_out);
 }
 
 // ConditionalGeneration::encode_speaker on a mel the caller already holds (Model::create_voice_clone_prompt_from_mel,
 // model/mod.rs:579-612): mel_in [B][frames_stride][128] f32 (log-mel, frames x mels), n_frames[b] valid frames.
 void run_speaker_embed_mel(Model& m, const float* mel_in, const int* n_frames, int B, int frames_stride, float* emb_out) {
+    std::lock_guard<std::mutex> lock(m.locks->speaker);  // sessions of one model share these workspaces
     QTTS_CHECK(B >= 1 && frames_stride >= 1, ERR_BAD_ARG, "speaker encoder: bad mel batch shape");
     for (int u = 0; u < B; ++u) QTTS_CHECK(n_frames[u] >= 1 && n_frames[u] <= frames_stride, ERR_BAD_ARG, "speaker encoder: n_frames out of range");
     speaker_embed_impl(m, nullptr, nullptr, 0, mel_in, n_frames, frames_stride, B, emb_out);

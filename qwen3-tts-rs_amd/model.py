@@ -169,9 +169,31 @@ class Model:
         self.last_timing = None
         self.text_processor = None  # text.TextProcessor; set by ModelLoader when the directory holds tokenizer.json
 
+    def open_session(self) -> "Model":
+        """A second decode stream on this model (qtts_session_open): same weights, its own HIP stream, KV caches, workspaces
+        and frame graph.  The returned object has every run-time method of Model (generate, decode_output, open_codec_stream,
+        ...) and may be driven from another host thread; close it before closing the model."""
+        if not self._finalized:
+            raise QttsError(-5, "open_session: finalize the model first")
+        ses = Model.__new__(Model)
+        ses.lib = self.lib
+        ses.config, ses.codec_config, ses.generate_defaults = self.config, self.codec_config, self.generate_defaults
+        ses.dtype = self.dtype
+        ses._ctx = C.c_void_p()          # borrowed from the parent: never shut down by the session
+        ses._parent = self
+        ses._m = C.c_void_p()
+        check(self.lib.qtts_session_open(self._m, C.byref(ses._m)))
+        ses._finalized = True
+        ses.last_timing = None
+        ses.text_processor = self.text_processor
+        return ses
+
     def close(self):
         if getattr(self, "_m", None) is not None and self._m:
-            self.lib.qtts_model_free(self._m)
+            if getattr(self, "_parent", None) is not None:
+                self.lib.qtts_session_close(self._m)
+            else:
+                self.lib.qtts_model_free(self._m)
             self._m = C.c_void_p()
         if getattr(self, "_ctx", None) is not None and self._ctx:
             self.lib.qtts_shutdown(self._ctx)
