@@ -7,10 +7,14 @@ waveforms on the host).  Weights are random-init of that architecture, texts are
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python bench.py --gpus N ...            (no launcher: the script starts its N ranks itself)
 
-Every rank holds full weight replicas and decodes its own utterances (no collective on the data path); within a rank
-`--pipeline` batches are in flight at once, each on its own HIP stream, and a step is one batch through the whole path.
-Rank 0 prints one JSON line.  The CPU oracle is timed on a bounded sample as a reported baseline (rank 0, N = 1 only)."""
+Every rank holds one full set of weights and decodes its own utterances (no collective on the data path); within a rank
+`--pipeline` batches are in flight at once, each in a decode session with its own HIP stream, and a step is one batch through
+the whole path.  `--mode strong` fixes the total work instead: `--utterances` voice-clone utterances (reference clip -> mel ->
+speaker encoder -> x-vector prompt -> decode -> codec) are dealt to the ranks by shard.assign_utterances, a step is one pass
+over all of them.  Rank 0 prints one JSON line.  The CPU oracle is timed on a bounded sample as a reported baseline (rank 0,
+N = 1 only)."""
 import argparse
 import json
 import os
@@ -51,15 +55,43 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=96)
     ap.add_argument("--first-frames", type=int, default=25,
                     help="frames of the first audio chunk (2 s): decoded as soon as they exist, while generation continues")
+    ap.add_argument("--mode", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch utterances per GPU per step; strong: --utterances voice-clone utterances in total per step, "
+                         "dealt to the ranks")
+    ap.add_argument("--utterances", type=int, default=256, help="strong mode: utterances per step over all ranks")
+    ap.add_argument("--dump-codes", default=None, help="rank 0 writes {utterance index: crc32 of its codes} of the last step here (json)")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """--gpus N without a launcher: start the N ranks as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
+    torch.distributed.run would set them), pass rank 0's JSON line through and return the worst exit code.  The parent never
+    touches the GPU."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for line in out.splitlines():   # the contract line to stdout, anything a library printed there to stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
+    return max(abs(c) for c in codes)
 
 
 def build_model(args, device):
     import torch
     from qwen3_tts_rs_amd import LoaderConfig, Model, synth
-    cfg, ccfg, tmpl = synth.shape_set(args.shape)
+    clone = args.mode == "strong"
+    cfg, ccfg, tmpl = synth.shape_set(args.shape, "base" if clone else "custom_voice")
     m = Model(cfg, None if args.no_codec else ccfg, LoaderConfig(dtype=args.dtype, device=device))
-    keys = synth.talker_keys(cfg) + ([] if args.no_codec else synth.codec_keys(ccfg))
+    keys = synth.talker_keys(cfg) + (synth.speaker_keys(cfg) if clone else []) + ([] if args.no_codec else synth.codec_keys(ccfg))
     for k, t in synth.iter_weights_torch(keys, SEED, f"cuda:{device}", args.dtype == "bf16"):
         m.load_tensor(k, t)
         del t
@@ -68,15 +100,34 @@ def build_model(args, device):
     return m, cfg, ccfg, tmpl
 
 
+def text_len(u):
+    return 8 + (u * 37 + 11) % 57                      # text content length in [8, 64]
+
+
 def make_requests(args, tmpl, rank):
     from qwen3_tts_rs_amd import GenerationRequest, synth
     reqs = []
     for b in range(args.batch):
         u = rank * args.batch + b                      # global utterance index
-        n = 8 + (u * 37 + 11) % 57                     # text content length in [8, 64]
-        reqs.append(GenerationRequest(text_ids=synth.synthetic_text_ids(tmpl, n, u), language="english", speaker="speaker1",
+        reqs.append(GenerationRequest(text_ids=synth.synthetic_text_ids(tmpl, text_len(u), u), language="english", speaker="speaker1",
                                       seed=None if args.greedy else 42 + u))
     return reqs
+
+
+def reference_clip(u):
+    """Synthetic reference audio of utterance u: 3.0 - 9.9 s at 24 kHz, a few sines under noise."""
+    n = 72000 + 641 * (u % 257)
+    rng = np.random.default_rng(1000 + u)
+    t = np.arange(n, dtype=np.float32) / 24000.0
+    x = sum(a * np.sin(2 * np.pi * f * t + p) for a, f, p in zip((0.3, 0.2, 0.1), (110.0 + 7 * (u % 13), 440.0, 1870.0), rng.uniform(0, 6.28, 3)))
+    return (x + 0.02 * rng.standard_normal(n)).astype(np.float32)
+
+
+def strong_share(args, rank, world):
+    """This rank's utterances of the fixed job (ascending global indices): longest-first assignment on text length + clip length."""
+    from qwen3_tts_rs_amd.shard import assign_utterances
+    costs = [text_len(u) + (72000 + 641 * (u % 257)) / 1920.0 for u in range(args.utterances)]
+    return assign_utterances(costs, world)[rank]
 
 
 def cpu_baseline(args, cfg, ccfg, tmpl):
@@ -125,6 +176,8 @@ def reduce_job(elapsed: float, audio_s: float, dist, device: str):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -146,11 +199,14 @@ def main():
 
     import threading
     from qwen3_tts_rs_amd import SamplingConfig, synth
-    P = max(1, min(args.pipeline, args.steps))
+    P = max(1, args.pipeline if args.mode == "strong" else min(args.pipeline, args.steps))
     # one set of weights per GPU; every batch in flight beyond the first runs in a session of the same model (its own HIP
     # stream, KV caches, workspaces and frame graph)
     m, cfg, ccfg, tmpl = build_model(args, local)
     models = [m] + [m.open_session() for _ in range(P - 1)]
+    strong = args.mode == "strong"
+    mine = strong_share(args, rank, world) if strong else []
+    clips = [reference_clip(u) for u in mine]            # host audio, prepared outside the timed region like the texts
     reqs = make_requests(args, tmpl, rank)
     sampling = SamplingConfig.cli_greedy() if args.greedy else SamplingConfig()
 
@@ -165,7 +221,7 @@ def main():
 
     csize = ccfg["decoder_config"]["codebook_size"]
 
-    def step(mod, record):
+    def step(mod, record, reqs=reqs):
         t_s = time.perf_counter()
         first_ms = []
 
@@ -195,14 +251,44 @@ def main():
                 out_last[0] = out
         return out, wavs
 
+    codes_crc = {}
+    probe = [reqs]   # one batch of requests for the eager profiling pass after the timed region
+
+    def strong_batches():
+        """One pass over this rank's utterances: reference clips -> x-vectors on the device (mel + speaker encoder), then
+        batches of --batch utterances."""
+        from qwen3_tts_rs_amd import GenerationRequest
+        import zlib
+        emb = m.extract_speaker_embedding(clips) if mine else np.zeros((0, 1), np.float32)
+        out = []
+        for i in range(0, len(mine), args.batch):
+            idx = mine[i:i + args.batch]
+            out.append((idx, [GenerationRequest(text_ids=synth.synthetic_text_ids(tmpl, text_len(u), u), language="english",
+                                                speaker_embed=emb[i + j], seed=None if args.greedy else 42 + u) for j, u in enumerate(idx)]))
+        return out, zlib.crc32
+
     def run_steps(n_steps, record):
-        # steps are dealt round-robin to the in-flight slots; every slot runs its steps back to back on its own stream
+        # weak: steps are dealt round-robin to the in-flight slots; every slot runs its steps back to back on its own stream.
+        # strong: every step is one pass over the rank's share, its batches dealt to the slots the same way.
         errs = []
+        if strong:
+            work = []
+            for _ in range(n_steps):
+                batches, crc = strong_batches()
+                work += batches
+            if work:
+                probe[0] = work[0][1]
+        else:
+            work = [(None, reqs)] * n_steps
 
         def worker(w):
             try:
-                for _ in range(w, n_steps, P):
-                    step(models[w], record)
+                for idx, rq in work[w::P]:
+                    out, _ = step(models[w], record, rq)
+                    if idx is not None and record:
+                        with lock:
+                            for j, u in enumerate(idx):
+                                codes_crc[u] = int(crc(np.ascontiguousarray(out.codes[j, :out.effective_lengths[j]]).tobytes()))
             except Exception as ex:  # surfaced after the join
                 errs.append(ex)
 
@@ -222,11 +308,18 @@ def main():
     elapsed = time.perf_counter() - t0
 
     elapsed_max, audio_total = reduce_job(elapsed, stats["audio_s"], dist if world > 1 else None, f"cuda:{local}" if backend == "nccl" else "cpu")
+    if strong and args.dump_codes:
+        from qwen3_tts_rs_amd.shard import gather_results
+        got = gather_results(sorted(codes_crc), [codes_crc[u] for u in sorted(codes_crc)], args.utterances, dist if world > 1 else None)
+        if rank == 0:
+            with open(args.dump_codes, "w") as f:
+                json.dump({str(u): c for u, c in enumerate(got)}, f)
 
     result = None
     if rank == 0:
         es = 2 if args.dtype == "bf16" else 4
-        frames_run = max(stats["frames"] - args.steps, 1)       # the first frame of each call comes out of the prefill
+        calls = len(stats["step_ms"])                             # generate calls of this rank in the timed region
+        frames_run = max(stats["frames"] - calls, 1)              # the first frame of each call comes out of the prefill
         ms_per_frame = stats["frames_ms"] / frames_run            # per stream, HIP events around each call's frame loop
         avg_ctx = 40 + args.frames / 2.0                          # mean prompt (~40 positions) + half the generated frames
         bytes_frame = synth.decode_bytes_per_frame(cfg, args.batch, avg_ctx, es)
@@ -248,8 +341,8 @@ def main():
         roofline["mfma_utilisation"] = {"achieved": round(mfma_ach, 1), "peak": mfma_peak, "unit": "TFLOP/s",
                                         "frac": round(mfma_ach / mfma_peak, 4), "flops_per_launch": fl_frame}
         # dominant weight-streaming GEMM, timed launch by launch with HIP events in an eager pass after the timed region
-        m.generate(reqs, sampling, 9, use_graph=False, profile_gemm=True)
-        prof = [p for p in m.gemm_profile() if p["M"] == args.batch]
+        m.generate(probe[0], sampling, 9, use_graph=False, profile_gemm=True)
+        prof = [p for p in m.gemm_profile() if p["M"] == len(probe[0])]
         gemm = None
         if prof:
             top = max(prof, key=lambda p: p["total_us"])
@@ -282,12 +375,16 @@ def main():
         result = {
             "metric": "audio-sec generated/sec", "value": round(audio_total / elapsed_max, 2), "unit": "audio_s/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.shape} CustomVoice-shaped random-init model, batch {args.batch} synthetic texts per GPU, "
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": (f"{args.shape} Base-shaped random-init model, {args.utterances} voice-clone utterances in total per step "
+                                    f"(3-10 s reference clips -> mel -> speaker encoder -> x-vector prompts), dealt to the ranks, decoded "
+                                    f"in batches of {args.batch}, " if strong else
+                                    f"{args.shape} CustomVoice-shaped random-init model, batch {args.batch} synthetic texts per GPU, ") +
                                    f"{args.frames} frames each ({'greedy' if args.greedy else 'seeded sampling'}, "
                                    f"{'EOS as sampled' if args.natural_eos else 'EOS suppressed up to that length'}), codec decode "
                                    f"{'off' if args.no_codec else 'to 24 kHz waveforms on the host'}",
                        "batch_per_gpu": args.batch, "frames": args.frames, "fixed_length": not args.natural_eos,
+                       "utterances_total": args.utterances if strong else args.batch * world,
                        "parallelism": f"dp{world} (per-utterance)"},
             # first audio = the first `first_frames` frames through a streaming decode session (final samples), decoded and on the
             # host while generation continues; full utterance = the reference's own (non-streaming) definition

@@ -144,3 +144,16 @@ def test_lpt_assignment_balances_and_is_deterministic():
     assert assign_utterances([], 2) == [[], []]
     out = gather_results([2, 0], ["c", "a"], 3)
     assert out == ["a", None, "c"]
+
+
+def test_strong_scaling_job_is_dealt_exactly_once():
+    """bench.py --mode strong: every utterance of the fixed job goes to exactly one rank, shares are balanced."""
+    import types
+    import bench
+    args = types.SimpleNamespace(utterances=256)
+    for world in (1, 2, 4, 8):
+        shares = [bench.strong_share(args, r, world) for r in range(world)]
+        assert sorted(u for s in shares for u in s) == list(range(256))
+        assert max(len(s) for s in shares) - min(len(s) for s in shares) <= 1
+    clip = bench.reference_clip(5)
+    assert clip.dtype == np.float32 and 72000 <= len(clip) <= 72000 + 641 * 256 and np.abs(clip).max() < 1.0
