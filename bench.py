@@ -326,13 +326,25 @@ def main():
         # frame loops of the in-flight batches overlap (and overlap codec decodes): the bandwidth the decode frames achieve
         # together is bounded below by their algorithmic bytes over the whole timed region
         achieved = bytes_frame * frames_run / elapsed / 1e9
+        # HBM-side bytes of one frame from the PMC counters: collected once per round with tools/dev/pmc_frame.sh (rocprofv3 cannot
+        # follow a hipGraph, so the passes run the frame eagerly), committed under profiles/ and quoted here when this run is the
+        # configuration they were taken on
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r02_frame_traffic.json")
+        if os.path.exists(tpath) and args.shape == "S17" and args.batch == 64 and args.dtype == "bf16" and not strong:
+            traffic = json.load(open(tpath)).get("traffic_bytes")
         roofline = {"bound": "hbm", "kernel": "decode frame (one hipGraph launch: talker step + code-predictor passes + sampling)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": None, "bytes_per_launch": bytes_frame, "avg_launch_ms": round(ms_per_frame, 4),
+                    "traffic": traffic, "bytes_per_launch": bytes_frame, "avg_launch_ms": round(ms_per_frame, 4),
                     "launches": frames_run, "streams_in_flight": P,
                     "note": "achieved = algorithmic bytes of every decode frame in the timed region / wall time of the region "
                             "(includes the overlapped prefill and codec phases); avg_launch_ms is per stream",
-                    "weight_bytes_per_launch": synth.weight_bytes_per_frame(cfg, es)["total"]}
+                    "weight_bytes_per_launch": synth.weight_bytes_per_frame(cfg, es)["total"],
+                    # the same bytes over the duration of one frame launch of ONE stream (HIP events around each call's frame loop):
+                    # the per-step fraction; with several streams in flight their frames overlap, so this understates the chip
+                    "per_step": {"achieved": round(bytes_frame / (ms_per_frame * 1e-3) / 1e9, 1),
+                                 "frac": round(bytes_frame / (ms_per_frame * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                 "avg_launch_ms": round(ms_per_frame, 4), "streams_sharing_the_gpu": P}}
         # the same frames priced against the matrix cores: at 64 rows a weight-streaming GEMM does 64 FLOP per byte, far below the
         # ridge (~310 FLOP/B), so this is a reported utilisation, not the bound
         fl_frame = synth.decode_flops_per_frame(cfg, args.batch, avg_ctx)

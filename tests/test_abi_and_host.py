@@ -157,3 +157,37 @@ def test_strong_scaling_job_is_dealt_exactly_once():
         assert max(len(s) for s in shares) - min(len(s) for s in shares) <= 1
     clip = bench.reference_clip(5)
     assert clip.dtype == np.float32 and 72000 <= len(clip) <= 72000 + 641 * 256 and np.abs(clip).max() < 1.0
+
+
+def test_rust_sys_crate_declares_the_whole_header():
+    """qwen-tts-hip-sys/src/lib.rs: every function of include/qtts.h, every struct field in the header's order."""
+    rs = open(os.path.join(ROOT, "qwen-tts-hip-sys", "src", "lib.rs")).read()
+    for f in ("Cargo.toml", "build.rs"):
+        assert os.path.exists(os.path.join(ROOT, "qwen-tts-hip-sys", f))
+    declared = set(re.findall(r"pub fn (qtts_[a-z_0-9]+)\s*\(", rs))
+    assert declared == set(header_symbols())
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "qtts.h")).read(), flags=re.S)
+    ctype = {"int": "c_int", "double": "c_double", "uint64_t": "u64", "const char*": "*const c_char", "const uint32_t*": "*const u32",
+             "const float*": "*const c_float", "uint32_t*": "*mut u32", "float*": "*mut c_float", "void*": "*mut c_void"}
+    for cname in ("qtts_request", "qtts_sampling", "qtts_codes_out", "qtts_gen_debug"):
+        body = re.search(r"typedef struct \{([^}]*)\}\s*" + cname + ";", hdr).group(1)
+        c_fields = []
+        for d in body.split(";"):
+            d = " ".join(d.split())
+            if not d:
+                continue
+            if "(*" in d:                                   # the callback pointer
+                c_fields.append((re.search(r"\(\*(\w+)\)", d).group(1), None))
+                continue
+            m = re.match(r"(.*?)\s*(\w+)$", d)
+            c_fields.append((m.group(2), m.group(1).replace(" *", "*")))
+        rbody = re.search(r"pub struct " + cname + r" \{(.*?)\n\}", rs, flags=re.S).group(1)
+        r_fields = re.findall(r"pub (\w+): ([^,\n]+),", rbody)
+        assert [f for f, _ in r_fields] == [f for f, _ in c_fields], cname
+        for (f, rt), (_, ct) in zip(r_fields, c_fields):
+            if ct is not None:
+                assert rt.strip() == ctype[ct], f"{cname}.{f}: {rt} vs {ct}"
+    feat = open(os.path.join(ROOT, "qwen-tts-hip-sys", "qwen_tts_hip_feature", "hip.rs")).read()
+    for fn in ("qtts_model_create", "qtts_model_load_tensor", "qtts_model_finalize", "qtts_generate", "qtts_codec_decode", "qtts_encode_audio",
+               "qtts_mel", "qtts_speaker_embed", "qtts_speaker_embed_mel", "qtts_session_open", "qtts_codec_stream_push"):
+        assert "sys::" + fn in feat, fn
