@@ -149,6 +149,16 @@ int qtts_generate(qtts_model* m, const qtts_request* reqs, int n, const qtts_sam
 int qtts_generate_ex(qtts_model* m, const qtts_request* reqs, int n, const qtts_sampling* s, int max_new_tokens,
                      qtts_codes_out* outs, const qtts_gen_debug* dbg);
 
+/* Continuous batching (no counterpart in the reference, whose batch runs until its last row is done): n utterances are decoded
+ * through at most `slots` rows.  A row is retired once it has produced the frame with its EOS or max_new_tokens frames, and its
+ * slot is prefilled with the next queued utterance while the other rows keep decoding (rows are polled every 8 frames).  Every
+ * utterance gets what a qtts_generate call with that request alone returns: outs[i].num_steps = its own frame count (the EOS
+ * frame included, 0 if its first token is EOS), effective_len as there; with a seeded request the draws are the same stream.
+ * outs[i].codes holds max_new_tokens * groups u32 as for qtts_generate.  dbg may carry use_graph, profile_gemm and min_new_tokens;
+ * traces and the first-chunk hook are not available here. */
+int qtts_generate_continuous(qtts_model* m, const qtts_request* reqs, int n, const qtts_sampling* s, int max_new_tokens,
+                             int slots, qtts_codes_out* outs, const qtts_gen_debug* dbg);
+
 /* Timing of the last qtts_generate_ex call (milliseconds, HIP events on the context stream):
  * out[0] prompt+prefill, out[1] frame loop, out[2] summed GEMM kernel time (profile_gemm only),
  * out[3] GEMM launches timed, out[4] algorithmic weight bytes those launches streamed, out[5] frames run,

@@ -138,6 +138,16 @@ extern "C" {
         outs: *mut qtts_codes_out,
         dbg: *const qtts_gen_debug,
     ) -> c_int;
+    pub fn qtts_generate_continuous(
+        m: *mut qtts_model,
+        reqs: *const qtts_request,
+        n: c_int,
+        s: *const qtts_sampling,
+        max_new_tokens: c_int,
+        slots: c_int,
+        outs: *mut qtts_codes_out,
+        dbg: *const qtts_gen_debug,
+    ) -> c_int;
     pub fn qtts_last_timing(m: *mut qtts_model, out: *mut c_double, n: c_int) -> c_int;
 
     pub fn qtts_gemm_profile(m: *mut qtts_model, rows: *mut c_double, cap_rows: c_int, n_rows: *mut c_int) -> c_int;

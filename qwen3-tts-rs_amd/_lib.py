@@ -52,7 +52,8 @@ EXPORTS = ["qtts_init", "qtts_shutdown", "qtts_last_error", "qtts_stream", "qtts
            "qtts_last_timing", "qtts_codec_decode", "qtts_mel", "qtts_speaker_embed", "qtts_model_info",
            "qtts_gemm_profile", "qtts_bench_gemm", "qtts_bench_stream", "qtts_encode_audio",
            "qtts_speaker_embed_mel", "qtts_codec_stream_open", "qtts_codec_stream_push", "qtts_codec_stream_close",
-           "qtts_mel_noalloc", "qtts_mel_noalloc_capacity", "qtts_session_open", "qtts_session_close", "qtts_session_stream"]
+           "qtts_mel_noalloc", "qtts_mel_noalloc_capacity", "qtts_session_open", "qtts_session_close", "qtts_session_stream",
+           "qtts_generate_continuous"]
 
 _lib = None
 
@@ -84,6 +85,8 @@ def load():
     lib.qtts_session_stream.restype = C.c_void_p
     lib.qtts_generate.argtypes = [C.c_void_p, C.POINTER(Request), C.c_int, C.POINTER(Sampling), C.c_int, C.POINTER(CodesOut)]
     lib.qtts_generate_ex.argtypes = lib.qtts_generate.argtypes + [C.POINTER(GenDebug)]
+    lib.qtts_generate_continuous.argtypes = [C.c_void_p, C.POINTER(Request), C.c_int, C.POINTER(Sampling), C.c_int, C.c_int,
+                                             C.POINTER(CodesOut), C.POINTER(GenDebug)]
     lib.qtts_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
     lib.qtts_codec_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_int64, C.c_void_p]

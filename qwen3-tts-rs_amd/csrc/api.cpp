@@ -157,6 +157,14 @@ int qtts_generate(qtts_model* m, const qtts_request* reqs, int n, const qtts_sam
     return qtts_generate_ex(m, reqs, n, s, max_new_tokens, outs, nullptr);
 }
 
+int qtts_generate_continuous(qtts_model* m, const qtts_request* reqs, int n, const qtts_sampling* s, int max_new_tokens, int slots,
+                             qtts_codes_out* outs, const qtts_gen_debug* dbg) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(m, ERR_BAD_ARG, "qtts_generate_continuous: null model");
+    run_generate_continuous(m->m, reqs, n, s, max_new_tokens, slots, outs, dbg);
+    QTTS_API_END
+}
+
 int qtts_last_timing(qtts_model* m, double* out, int n) {
     QTTS_API_BEGIN
     QTTS_CHECK(m && out && n >= 0, ERR_BAD_ARG, "qtts_last_timing: null argument");

@@ -443,8 +443,8 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
             rope_table_simple(c.head_dim, c.rope_theta, n, cs, sn);
             s.xf.cos.alloc(cs.size() * 4);
             s.xf.sin.alloc(sn.size() * 4);
-            QTTS_HIP(hipMemcpy(s.xf.cos.p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
-            QTTS_HIP(hipMemcpy(s.xf.sin.p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+            copy_sync(s.xf.cos.p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice, m.ctx->stream);
+            copy_sync(s.xf.sin.p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice, m.ctx->stream);
             s.xf.max_pos = n;
         }
         Runner run(m, s.ws, nullptr);
@@ -702,7 +702,7 @@ void run_codec_decode(Model& m, const uint32_t* codes, const int* lens, int B, i
     if (pieces.empty()) return;
     std::stable_sort(pieces.begin(), pieces.end(), [](const Piece& a, const Piece& b) { return a.len > b.len; });
     s.codes.ensure((size_t)B * T_max * s.Q * 4);
-    QTTS_HIP(hipMemcpy(s.codes.p, codes, (size_t)B * T_max * s.Q * 4, hipMemcpyHostToDevice));
+    copy_sync(s.codes.p, codes, (size_t)B * T_max * s.Q * 4, hipMemcpyHostToDevice, m.ctx->stream);
     // ---- groups bounded by a scratch budget
     static const size_t budget = (size_t)(getenv("QTTS_CODEC_SCRATCH_MB") ? std::max(64, atoi(getenv("QTTS_CODEC_SCRATCH_MB"))) : 32768) << 20;
     Decoder dec(m);
@@ -801,7 +801,7 @@ void codec_stream_push(CodecStream& sc, const uint32_t* codes, int n, float* wav
         std::memcpy(dst + (size_t)C * Q, codes + (size_t)b * n * Q, (size_t)n * Q * 4);
     }
     s.codes.ensure(all.size() * 4);
-    QTTS_HIP(hipMemcpy(s.codes.p, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+    copy_sync(s.codes.p, all.data(), all.size() * 4, hipMemcpyHostToDevice, m.ctx->stream);
     std::vector<Piece> ps;
     for (int b = 0; b < B; ++b) ps.push_back(Piece{b, 0, T, 0, 0});
     m.timing[6] = 0;

@@ -33,6 +33,13 @@ constexpr int ERR_BAD_ARG = -1, ERR_HIP = -2, ERR_OOM = -3, ERR_SHAPE = -4, ERR_
         if (!(cond)) throw ::qtts::Error((code), (msg));     \
     } while (0)
 
+// Blocking copy on `st`.  Run-time paths never use the legacy stream (plain hipMemcpy): it synchronises with every blocking
+// stream of the process, which fails while another session captures its frame graph.
+inline void copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+    QTTS_HIP(hipMemcpyAsync(dst, src, bytes, kind, st));
+    QTTS_HIP(hipStreamSynchronize(st));
+}
+
 // HIP event owned by a scope: destroyed on every way out, including the exceptions QTTS_HIP / QTTS_CHECK throw.
 struct ScopedEvent {
     hipEvent_t e = nullptr;

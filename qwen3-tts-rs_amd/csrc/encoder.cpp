@@ -317,8 +317,8 @@ void run_encode_audio(Model& m, const float* audio, const int* n_samples, int B,
             rope_table_simple(ENC_HD, 10000.0, n, cs, sn);
             s.cos.alloc(cs.size() * 4);
             s.sin.alloc(sn.size() * 4);
-            QTTS_HIP(hipMemcpy(s.cos.p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice));
-            QTTS_HIP(hipMemcpy(s.sin.p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+            copy_sync(s.cos.p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice, m.ctx->stream);
+            copy_sync(s.sin.p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice, m.ctx->stream);
             s.max_pos = n;
         }
         Runner run(m, s.ws, nullptr);

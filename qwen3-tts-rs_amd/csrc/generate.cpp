@@ -3,6 +3,11 @@
 // replay per generated frame covering the talker decode step, cb0 sampling, the G-1 code-predictor
 // passes (nn/code_predictor.rs:433-531) and the next-input embedding sum.  No host round trip
 // happens inside a frame; the host only polls the per-row EOS steps every few frames.
+//
+// Two drivers share every piece: the reference's batch (n utterances = n rows, all rows run until the last one is done),
+// and continuous batching (n utterances through a fixed number of row slots: a row that has produced its EOS frame or
+// max_new_tokens frames is retired at the next poll and its slot is prefilled with the next queued utterance while the other
+// rows keep decoding; every utterance gets exactly the frames a batch of one would have produced for it).
 #include "generate.hpp"
 #include "runner.hpp"
 
@@ -66,7 +71,7 @@ struct GenState {
     DevBuf text_rows, extra, trailing, tts_pad_dummy;
     DevBuf ibuf;                             // int scratch: ids / descriptors
     DevBuf toks_prompt, toks_dec, toks_cp;
-    DevBuf row_len, step, eos_step, hist, uniforms, codes, trailing_len;
+    DevBuf row_len, step, eos_step, active, hist, uniforms, codes, trailing_len, tts_pad;
     DevBuf trace_logits, trace_hidden, trace_cp;
     StackRun talker, cp;
     size_t cap_rows = 0;
@@ -78,42 +83,39 @@ struct GenState {
     }
 };
 
-void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling* sp, int max_new, qtts_codes_out* outs,
-                  const qtts_gen_debug* dbg) {
-    QTTS_CHECK(m.finalized && m.codec_head.p != nullptr, ERR_STATE, "generate: model has no talker weights or is not finalized");
-    QTTS_CHECK(reqs && outs && sp && n >= 1 && n <= 1024, ERR_BAD_ARG, "generate: bad batch");
-    QTTS_CHECK(max_new >= 1 && max_new <= 32768, ERR_BAD_ARG, "generate: max_new_tokens out of range");
-    QTTS_HIP(hipSetDevice(m.ctx->device));
-    const ModelCfg& c = m.cfg;
-    const int B = n, H = c.talker.hidden, Ht = c.text_hidden, G = c.groups, V = c.vocab, Vc = c.cp_vocab, Hc = c.cp.hidden;
-    if (!m.gen) m.gen.reset(new GenState());
-    GenState& g = *m.gen;
-    Runner R(m, g.ws, &g.timer);
-    hipStream_t st = R.st;
-    const int dt = m.dtype;
-    const size_t es = R.es;
-    const bool use_graph = dbg ? dbg->use_graph != 0 : true;
-    const bool split = split_activations(dt), split_cp = split_level(dt) >= 2;
-    g.timer.enabled = dbg && dbg->profile_gemm && !use_graph;
-    g.timer.used = 0;
-    g.timer.bytes = 0;
-    g.timer.shape.clear();
+// Host-side plan of the prompts of a group of requests (generation.rs:452-799): flattened position descriptors, the text ids
+// whose projections the prompts and the trailing text need, speaker vectors / ICL rows, one Tok per prompt position.
+// Request ids[i] occupies KV-cache row slots[i].
+struct PromptPlan {
+    std::vector<int> text_ids;                 // rows 0, 1, 2 of the projected-text buffer are tts_bos, tts_eos, tts_pad
+    std::vector<int> p_text, p_codec, p_extra;  // flattened prompt position descriptors
+    std::vector<Tok> p_toks;
+    std::vector<int> row_P, trail_len;
+    std::vector<std::vector<int>> trail_idx;
+    std::vector<float> extra_rows;
+    std::vector<int> icl_codes, icl_rows;      // reference frames whose embedding sums are computed on the device
+};
 
-    // ------------------------------------------------------------------ host-side prompt planning
-    std::vector<int> text_ids = {c.tts_bos, c.tts_eos, c.tts_pad};  // rows 0,1,2 of the projected-text buffer
+static void plan_prompts(const ModelCfg& c, const qtts_request* reqs, const std::vector<int>& ids, const std::vector<int>& slots, PromptPlan& pl) {
+    const int B = (int)ids.size(), H = c.talker.hidden, G = c.groups, V = c.vocab, Vc = c.cp_vocab;
+    std::vector<int>& text_ids = pl.text_ids;
+    std::vector<int>&p_text = pl.p_text, &p_codec = pl.p_codec, &p_extra = pl.p_extra;
+    std::vector<Tok>& p_toks = pl.p_toks;
+    std::vector<int>&row_P = pl.row_P, &trail_len = pl.trail_len;
+    std::vector<std::vector<int>>& trail_idx = pl.trail_idx;
+    std::vector<float>& extra_rows = pl.extra_rows;
+    std::vector<int>&icl_codes = pl.icl_codes, &icl_rows = pl.icl_rows;
+    text_ids = {c.tts_bos, c.tts_eos, c.tts_pad};
+    row_P.assign((size_t)B, 0);
+    trail_len.assign((size_t)B, 0);
+    trail_idx.assign((size_t)B, {});
     auto add_text = [&](uint32_t id) {
         QTTS_CHECK((int)id < c.text_vocab, ERR_BAD_ARG, "generate: text id outside the text vocabulary");
         text_ids.push_back((int)id);
         return (int)text_ids.size() - 1;
     };
-    std::vector<int> p_text, p_codec, p_extra;  // flattened prompt position descriptors
-    std::vector<Tok> p_toks;
-    std::vector<int> row_P(B), trail_len(B, 0);
-    std::vector<std::vector<int>> trail_idx((size_t)B);
-    std::vector<float> extra_rows;
-    std::vector<int> icl_codes, icl_rows;  // reference frames whose embedding sums are computed on the device
     for (int b = 0; b < B; ++b) {
-        const qtts_request& r = reqs[b];
+        const qtts_request& r = reqs[ids[(size_t)b]];
         QTTS_CHECK(r.text_ids && r.n_text >= 4, ERR_BAD_ARG, "generate: text_ids needs at least 4 tokens");
         const bool icl = r.ref_codes != nullptr && r.ref_T > 0 && r.ref_text_ids != nullptr && r.n_ref_text > 0;
         QTTS_CHECK(r.ref_T >= 0 && (r.ref_codes == nullptr) == (r.ref_T == 0), ERR_BAD_ARG, "generate: ref_codes and ref_T disagree");
@@ -205,18 +207,56 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         row_P[(size_t)b] = (int)(p_text.size() - first);
         for (int p = 0; p < row_P[(size_t)b]; ++p) {
             Tok t;
-            t.row = b;
+            t.row = slots[(size_t)b];
             t.pos = p;
             t.ctx_start = c.talker.window > 0 ? std::max(0, p + 1 - c.talker.window) : 0;
             t.ctx_len = p + 1 - t.ctx_start;
             p_toks.push_back(t);
         }
     }
-    const int Ttot = (int)p_toks.size(), Nt = (int)text_ids.size();
-    int Tt_max = 1;
-    for (int b = 0; b < B; ++b) Tt_max = std::max(Tt_max, trail_len[(size_t)b]);
-    int max_ctx = 0;
-    for (int b = 0; b < B; ++b) max_ctx = std::max(max_ctx, row_P[(size_t)b] + max_new);
+}
+
+// slots > 0: continuous batching of n utterances through `slots` rows (see the top of the file); slots == 0: the reference's batch
+static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_sampling* sp, int max_new, qtts_codes_out* outs,
+                          const qtts_gen_debug* dbg, int slots) {
+    QTTS_CHECK(m.finalized && m.codec_head.p != nullptr, ERR_STATE, "generate: model has no talker weights or is not finalized");
+    QTTS_CHECK(reqs && outs && sp && n >= 1 && (slots > 0 || n <= 1024) && n <= (1 << 20), ERR_BAD_ARG, "generate: bad batch");
+    QTTS_CHECK(slots >= 0 && slots <= 1024, ERR_BAD_ARG, "generate: row slots out of range");
+    QTTS_CHECK(max_new >= 1 && max_new <= 32768, ERR_BAD_ARG, "generate: max_new_tokens out of range");
+    QTTS_HIP(hipSetDevice(m.ctx->device));
+    const ModelCfg& c = m.cfg;
+    const bool streaming = slots > 0;                 // continuous batching
+    const int B = streaming ? std::min(slots, n) : n;  // rows of every launch
+    const int H = c.talker.hidden, Ht = c.text_hidden, G = c.groups, V = c.vocab, Vc = c.cp_vocab, Hc = c.cp.hidden;
+    if (!m.gen) m.gen.reset(new GenState());
+    GenState& g = *m.gen;
+    Runner R(m, g.ws, &g.timer);
+    hipStream_t st = R.st;
+    const int dt = m.dtype;
+    const size_t es = R.es;
+    const bool use_graph = dbg ? dbg->use_graph != 0 : true;
+    const bool split = split_activations(dt), split_cp = split_level(dt) >= 2;
+    g.timer.enabled = dbg && dbg->profile_gemm && !use_graph;
+    g.timer.used = 0;
+    g.timer.bytes = 0;
+    g.timer.shape.clear();
+    const bool trace_l = dbg && dbg->logits, trace_h = dbg && dbg->hidden, trace_c = dbg && dbg->cp_logits;
+    const bool tracing = trace_l || trace_h || trace_c;
+    QTTS_CHECK(!streaming || !(tracing || (dbg && dbg->chunk_cb)), ERR_BAD_ARG, "generate: traces and the first-chunk hook need the plain batch");
+
+    // ------------------------------------------------------------------ sizes over every request (the buffers the frame graph
+    // points at are allocated once: prompt length and trailing-text length of the longest utterance)
+    int Tt_max = 1, max_ctx = 0;
+    {
+        PromptPlan all;
+        std::vector<int> ids((size_t)n), rows((size_t)n, 0);
+        for (int i = 0; i < n; ++i) ids[(size_t)i] = i;
+        plan_prompts(c, reqs, ids, rows, all);
+        for (int i = 0; i < n; ++i) {
+            Tt_max = std::max(Tt_max, all.trail_len[(size_t)i]);
+            max_ctx = std::max(max_ctx, all.row_P[(size_t)i] + max_new);
+        }
+    }
 
     // ------------------------------------------------------------------ workspace
     const int chunk_rows = std::max(PREFILL_CHUNK, gemm_pad_rows(2 * B));
@@ -246,16 +286,14 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     const long lo_cp = split ? (long)(cp_rows * H) : 0;
     if (split) QTTS_HIP(hipMemsetAsync((char*)g.cp_in_t.p + (size_t)lo_cp * es, 0, cp_rows * H * es, st));
     g.cp_in_f.ensure(cp_rows * H * 4);
-    g.text_rows.ensure((size_t)Nt * H * 4);
-    g.extra.ensure(std::max<size_t>(extra_rows.size(), 1) * 4);
     g.trailing.ensure((size_t)B * Tt_max * H * 4);
-    g.ibuf.ensure(((size_t)Ttot * 3 + Nt + (size_t)B * Tt_max + 4 * B + 64) * 4);
-    g.toks_prompt.ensure((size_t)Ttot * sizeof(Tok));
+    g.tts_pad.ensure((size_t)H * 4);
     g.toks_dec.ensure((size_t)B * sizeof(Tok));
     g.toks_cp.ensure((size_t)(2 * B + (size_t)B * G) * sizeof(Tok));
     g.row_len.ensure((size_t)B * 4);
-    g.step.ensure(16);
+    g.step.ensure((size_t)B * 4);
     g.eos_step.ensure((size_t)B * 4);
+    g.active.ensure((size_t)B * 4);
     g.hist.ensure((size_t)B * V * 4);
     g.uniforms.ensure((size_t)B * max_new * G * 4);
     g.codes.ensure((size_t)B * max_new * G * 4);
@@ -277,61 +315,15 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         g.cp.kv = KVView{g.cp.pool.p, (size_t)B * cpage, CP_PAGE_TOKENS, c.cp.nkv, c.cp.d, 1, nullptr};
     }
 
-    // uniforms in the reference's draw order per utterance: frame by frame, cb0 first then codebooks 1..G-1
-    // (generation.rs:1055-1060, code_predictor.rs:468-472,517-522); a greedy stage consumes no draw.
-    if (sp->do_sample || sp->subtalker_do_sample) {
-        std::vector<float> u((size_t)B * max_new * G, 0.f);
-        for (int b = 0; b < B; ++b) {
-            uint64_t seed = reqs[b].seed;
-            if (!reqs[b].use_seed)
-                seed = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
-                           std::chrono::system_clock::now().time_since_epoch()).count() + (uint64_t)b * 0x9E3779B97F4A7C15ull;
-            HostMT rng((uint32_t)seed);
-            for (int s = 0; s < max_new; ++s) {
-                float* row = &u[((size_t)b * max_new + s) * G];
-                if (sp->do_sample) row[0] = rng.uniform();
-                if (sp->subtalker_do_sample)
-                    for (int j = 1; j < G; ++j) row[j] = rng.uniform();
-            }
-        }
-        QTTS_HIP(hipMemcpy(g.uniforms.p, u.data(), u.size() * 4, hipMemcpyHostToDevice));
-    }
-
     ScopedEvent ev0, ev1, ev2;
     QTTS_HIP(hipEventRecord(ev0, st));
-
-    // ------------------------------------------------------------------ upload descriptors
-    int* ib = g.ibuf.as<int>();
-    int* d_ptext = ib;
-    int* d_pcodec = ib + Ttot;
-    int* d_pextra = ib + 2 * Ttot;
-    int* d_textids = ib + 3 * Ttot;
-    int* d_trail = d_textids + Nt;
-    int* d_last_src = d_trail + B * Tt_max;
-    int* d_last_dst = d_last_src + B;
-    QTTS_HIP(hipMemcpyAsync(d_ptext, p_text.data(), (size_t)Ttot * 4, hipMemcpyHostToDevice, st));
-    QTTS_HIP(hipMemcpyAsync(d_pcodec, p_codec.data(), (size_t)Ttot * 4, hipMemcpyHostToDevice, st));
-    QTTS_HIP(hipMemcpyAsync(d_pextra, p_extra.data(), (size_t)Ttot * 4, hipMemcpyHostToDevice, st));
-    QTTS_HIP(hipMemcpyAsync(d_textids, text_ids.data(), (size_t)Nt * 4, hipMemcpyHostToDevice, st));
-    std::vector<int> trail_flat((size_t)B * Tt_max, 2);
-    for (int b = 0; b < B; ++b)
-        for (size_t i = 0; i < trail_idx[(size_t)b].size(); ++i) trail_flat[(size_t)b * Tt_max + i] = trail_idx[(size_t)b][i];
-    QTTS_HIP(hipMemcpyAsync(d_trail, trail_flat.data(), trail_flat.size() * 4, hipMemcpyHostToDevice, st));
-    QTTS_HIP(hipMemcpyAsync(g.toks_prompt.p, p_toks.data(), (size_t)Ttot * sizeof(Tok), hipMemcpyHostToDevice, st));
-    QTTS_HIP(hipMemcpyAsync(g.trailing_len.p, trail_len.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-    QTTS_HIP(hipMemcpyAsync(g.row_len.p, row_P.data(), (size_t)B * 4, hipMemcpyHostToDevice, st));
-    if (!extra_rows.empty()) QTTS_HIP(hipMemcpyAsync(g.extra.p, extra_rows.data(), extra_rows.size() * 4, hipMemcpyHostToDevice, st));
-    if (!icl_rows.empty()) {  // sum_ref_code_embeddings (generation.rs:242-273) into the extra rows
-        g.icl.ensure((icl_codes.size() + icl_rows.size()) * 4);
-        QTTS_HIP(hipMemcpyAsync(g.icl.p, icl_codes.data(), icl_codes.size() * 4, hipMemcpyHostToDevice, st));
-        QTTS_HIP(hipMemcpyAsync(g.icl.as<int>() + icl_codes.size(), icl_rows.data(), icl_rows.size() * 4, hipMemcpyHostToDevice, st));
-        launch_sum_code_rows(st, dt, m.codec_emb, (const void* const*)m.cp_emb_ptrs.p, g.icl.as<int>(), g.icl.as<int>() + icl_codes.size(),
-                             (int)icl_rows.size(), G, H, g.extra.as<float>());
-    }
-    QTTS_HIP(hipMemsetAsync(g.step.p, 0, 16, st));
+    QTTS_HIP(hipMemsetAsync(g.active.p, 0, (size_t)B * 4, st));
+    QTTS_HIP(hipMemsetAsync(g.step.p, 0, (size_t)B * 4, st));
+    QTTS_HIP(hipMemsetAsync(g.row_len.p, 0, (size_t)B * 4, st));
     QTTS_HIP(hipMemsetAsync(g.eos_step.p, 0xff, (size_t)B * 4, st));
-    QTTS_HIP(hipMemsetAsync(g.hist.p, 0, (size_t)B * V * 4, st));
+    QTTS_HIP(hipMemsetAsync(g.trailing_len.p, 0, (size_t)B * 4, st));
     QTTS_HIP(hipMemsetAsync(g.codes.p, 0, (size_t)B * max_new * G * 4, st));
+    QTTS_HIP(hipMemsetAsync(g.uniforms.p, 0, (size_t)B * max_new * G * 4, st));
     // code-predictor token descriptors: pass 0 = 2B tokens (position-major), unmasked => both attend 2 keys
     // (code_predictor.rs:455-460 + attention/mod.rs:413-417); pass j = B tokens at position j + 1.
     {
@@ -343,29 +335,101 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         QTTS_HIP(hipMemcpyAsync(g.toks_cp.p, ct.data(), ct.size() * sizeof(Tok), hipMemcpyHostToDevice, st));
         QTTS_HIP(hipStreamSynchronize(st));
     }
-
-    // ------------------------------------------------------------------ text projection (talker.rs:345-348, mlp.rs:149-160)
-    for (int o = 0; o < Nt; o += chunk_rows) {
-        const int M = std::min(chunk_rows, Nt - o);
-        launch_gather_rows(st, m.text_emb, dt, d_textids + o, g.ws.xn.p, dt, M, Ht, Ht);
-        int ks = R.ks_for(M, Ht, Ht);
-        R.gemm(m.fc1, g.ws.xn.p, M, Ht, Ht, ks, Ht);
-        launch_bias_act(st, g.ws.part.as<float>(), ks, R.kstride(M, Ht), m.fc1_b, 1, g.ws.act.p, dt, M, Ht, g.ws.lo_act);
-        ks = R.ks_for(M, H, Ht);
-        R.gemm(m.fc2, g.ws.act.p, M, H, Ht, ks, Ht, g.ws.lo_act);
-        launch_bias_act(st, g.ws.part.as<float>(), ks, R.kstride(M, H), m.fc2_b, 0, g.text_rows.as<float>() + (size_t)o * H, F32, M, H);
-    }
-    launch_gather_rows(st, g.text_rows.p, F32, d_trail, g.trailing.p, F32, B * Tt_max, H, H);
-    const float* tts_pad_row = g.text_rows.as<float>() + (size_t)2 * H;
-
-    // ------------------------------------------------------------------ prefill (generation.rs:884-903)
     void* hid_t = g.cp_in_t.p;                 // rows [0,B): post-norm hidden of each row's newest position
     float* hid_f = g.cp_in_f.as<float>();
-    {
+    const float* tts_pad_row = g.tts_pad.as<float>();
+
+    // ------------------------------------------------------------------ admission: requests ids[i] into rows slots[i]
+    // (prompt embedding assembly, talker prefill into the row's KV pages, the row's sampling state).  Uses the activation
+    // workspace, so it runs between frames; the rows that are decoding keep their state (hidden, KV, histories) untouched.
+    auto admit = [&](const std::vector<int>& ids, const std::vector<int>& rws) {
+        const int nb = (int)ids.size();
+        PromptPlan pl;
+        plan_prompts(c, reqs, ids, rws, pl);
+        const int Ttot = (int)pl.p_toks.size(), Nt = (int)pl.text_ids.size();
+        g.text_rows.ensure((size_t)Nt * H * 4);
+        g.extra.ensure(std::max<size_t>(pl.extra_rows.size(), 1) * 4);
+        g.ibuf.ensure(((size_t)Ttot * 3 + Nt + (size_t)nb * Tt_max + 4 * nb + 64) * 4);
+        g.toks_prompt.ensure((size_t)Ttot * sizeof(Tok));
+        // uniforms in the reference's draw order per utterance: frame by frame, cb0 first then codebooks 1..G-1
+        // (generation.rs:1055-1060, code_predictor.rs:468-472,517-522); a greedy stage consumes no draw.
+        if (sp->do_sample || sp->subtalker_do_sample) {
+            std::vector<float> u((size_t)max_new * G, 0.f);
+            for (int i = 0; i < nb; ++i) {
+                const qtts_request& rq = reqs[ids[(size_t)i]];
+                uint64_t seed = rq.seed;
+                if (!rq.use_seed)
+                    seed = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+                               std::chrono::system_clock::now().time_since_epoch()).count() + (uint64_t)ids[(size_t)i] * 0x9E3779B97F4A7C15ull;
+                HostMT rng((uint32_t)seed);
+                std::fill(u.begin(), u.end(), 0.f);
+                for (int s2 = 0; s2 < max_new; ++s2) {
+                    float* row = &u[(size_t)s2 * G];
+                    if (sp->do_sample) row[0] = rng.uniform();
+                    if (sp->subtalker_do_sample)
+                        for (int j = 1; j < G; ++j) row[j] = rng.uniform();
+                }
+                copy_sync(g.uniforms.as<float>() + (size_t)rws[(size_t)i] * max_new * G, u.data(), u.size() * 4, hipMemcpyHostToDevice, st);
+            }
+        }
+        int* ib = g.ibuf.as<int>();
+        int* d_ptext = ib;
+        int* d_pcodec = ib + Ttot;
+        int* d_pextra = ib + 2 * Ttot;
+        int* d_textids = ib + 3 * Ttot;
+        int* d_trail = d_textids + Nt;
+        int* d_last_src = d_trail + nb * Tt_max;
+        int* d_last_dst = d_last_src + nb;
+        QTTS_HIP(hipMemcpyAsync(d_ptext, pl.p_text.data(), (size_t)Ttot * 4, hipMemcpyHostToDevice, st));
+        QTTS_HIP(hipMemcpyAsync(d_pcodec, pl.p_codec.data(), (size_t)Ttot * 4, hipMemcpyHostToDevice, st));
+        QTTS_HIP(hipMemcpyAsync(d_pextra, pl.p_extra.data(), (size_t)Ttot * 4, hipMemcpyHostToDevice, st));
+        QTTS_HIP(hipMemcpyAsync(d_textids, pl.text_ids.data(), (size_t)Nt * 4, hipMemcpyHostToDevice, st));
+        std::vector<int> trail_flat((size_t)nb * Tt_max, 2);
+        for (int i = 0; i < nb; ++i)
+            for (size_t k = 0; k < pl.trail_idx[(size_t)i].size(); ++k) trail_flat[(size_t)i * Tt_max + k] = pl.trail_idx[(size_t)i][k];
+        QTTS_HIP(hipMemcpyAsync(d_trail, trail_flat.data(), trail_flat.size() * 4, hipMemcpyHostToDevice, st));
+        QTTS_HIP(hipMemcpyAsync(g.toks_prompt.p, pl.p_toks.data(), (size_t)Ttot * sizeof(Tok), hipMemcpyHostToDevice, st));
+        if (!pl.extra_rows.empty()) QTTS_HIP(hipMemcpyAsync(g.extra.p, pl.extra_rows.data(), pl.extra_rows.size() * 4, hipMemcpyHostToDevice, st));
+        if (!pl.icl_rows.empty()) {  // sum_ref_code_embeddings (generation.rs:242-273) into the extra rows
+            g.icl.ensure((pl.icl_codes.size() + pl.icl_rows.size()) * 4);
+            QTTS_HIP(hipMemcpyAsync(g.icl.p, pl.icl_codes.data(), pl.icl_codes.size() * 4, hipMemcpyHostToDevice, st));
+            QTTS_HIP(hipMemcpyAsync(g.icl.as<int>() + pl.icl_codes.size(), pl.icl_rows.data(), pl.icl_rows.size() * 4, hipMemcpyHostToDevice, st));
+            launch_sum_code_rows(st, dt, m.codec_emb, (const void* const*)m.cp_emb_ptrs.p, g.icl.as<int>(), g.icl.as<int>() + pl.icl_codes.size(),
+                                 (int)pl.icl_rows.size(), G, H, g.extra.as<float>());
+        }
+        // the rows' sampling state
+        for (int i = 0; i < nb; ++i) {
+            const int r = rws[(size_t)i];
+            const int one = 1, zero = 0, none = -1;
+            QTTS_HIP(hipMemcpyAsync(g.row_len.as<int>() + r, &pl.row_P[(size_t)i], 4, hipMemcpyHostToDevice, st));
+            QTTS_HIP(hipMemcpyAsync(g.trailing_len.as<int>() + r, &pl.trail_len[(size_t)i], 4, hipMemcpyHostToDevice, st));
+            QTTS_HIP(hipMemcpyAsync(g.step.as<int>() + r, &zero, 4, hipMemcpyHostToDevice, st));
+            QTTS_HIP(hipMemcpyAsync(g.eos_step.as<int>() + r, &none, 4, hipMemcpyHostToDevice, st));
+            QTTS_HIP(hipMemcpyAsync(g.active.as<int>() + r, &one, 4, hipMemcpyHostToDevice, st));
+            QTTS_HIP(hipMemsetAsync(g.hist.as<int>() + (size_t)r * V, 0, (size_t)V * 4, st));
+            QTTS_HIP(hipMemsetAsync(g.codes.as<unsigned>() + (size_t)r * max_new * G, 0, (size_t)max_new * G * 4, st));
+        }
+        QTTS_HIP(hipStreamSynchronize(st));  // the small host values above live on this stack frame
+        // text projection (talker.rs:345-348, mlp.rs:149-160)
+        for (int o = 0; o < Nt; o += chunk_rows) {
+            const int M = std::min(chunk_rows, Nt - o);
+            launch_gather_rows(st, m.text_emb, dt, d_textids + o, g.ws.xn.p, dt, M, Ht, Ht);
+            int ks = R.ks_for(M, Ht, Ht);
+            R.gemm(m.fc1, g.ws.xn.p, M, Ht, Ht, ks, Ht);
+            launch_bias_act(st, g.ws.part.as<float>(), ks, R.kstride(M, Ht), m.fc1_b, 1, g.ws.act.p, dt, M, Ht, g.ws.lo_act);
+            ks = R.ks_for(M, H, Ht);
+            R.gemm(m.fc2, g.ws.act.p, M, H, Ht, ks, Ht, g.ws.lo_act);
+            launch_bias_act(st, g.ws.part.as<float>(), ks, R.kstride(M, H), m.fc2_b, 0, g.text_rows.as<float>() + (size_t)o * H, F32, M, H);
+        }
+        for (int i = 0; i < nb; ++i)
+            launch_gather_rows(st, g.text_rows.p, F32, d_trail + (size_t)i * Tt_max, g.trailing.as<float>() + (size_t)rws[(size_t)i] * Tt_max * H, F32,
+                               Tt_max, H, H);
+        QTTS_HIP(hipMemcpyAsync(g.tts_pad.p, g.text_rows.as<float>() + (size_t)2 * H, (size_t)H * 4, hipMemcpyDeviceToDevice, st));
+        // prefill (generation.rs:884-903)
         std::vector<int> last_src, last_dst;
         int row_end = 0;
-        std::vector<int> ends((size_t)B);
-        for (int b = 0; b < B; ++b) { row_end += row_P[(size_t)b]; ends[(size_t)b] = row_end - 1; }
+        std::vector<int> ends((size_t)nb);
+        for (int i = 0; i < nb; ++i) { row_end += pl.row_P[(size_t)i]; ends[(size_t)i] = row_end - 1; }
         for (int o = 0; o < Ttot; o += chunk_rows) {
             const int M = std::min(chunk_rows, Ttot - o);
             launch_assemble(st, g.text_rows.as<float>(), d_ptext + o, m.codec_emb, dt, d_pcodec + o, g.extra.as<float>(),
@@ -376,8 +440,8 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
             R.stack(m.talker, M, g.toks_prompt.as<Tok>() + o, g.talker.kv, g.ws.act.p, g.ws.q.as<float>(), true, false, g.ws.lo_act);
             last_src.clear();
             last_dst.clear();
-            for (int b = 0; b < B; ++b)
-                if (ends[(size_t)b] >= o && ends[(size_t)b] < o + M) { last_src.push_back(ends[(size_t)b] - o); last_dst.push_back(b); }
+            for (int i = 0; i < nb; ++i)
+                if (ends[(size_t)i] >= o && ends[(size_t)i] < o + M) { last_src.push_back(ends[(size_t)i] - o); last_dst.push_back(rws[(size_t)i]); }
             if (!last_src.empty()) {
                 const int nl = (int)last_src.size();
                 QTTS_HIP(hipMemcpyAsync(d_last_src, last_src.data(), (size_t)nl * 4, hipMemcpyHostToDevice, st));
@@ -389,11 +453,19 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
                 QTTS_HIP(hipStreamSynchronize(st));  // last_src/last_dst are reused by the next chunk
             }
         }
+    };
+
+    // the first B utterances take the rows in order
+    int next_req = 0;
+    std::vector<int> row_req((size_t)B, -1);
+    {
+        std::vector<int> ids, rws;
+        for (int b = 0; b < B; ++b) { ids.push_back(next_req); rws.push_back(b); row_req[(size_t)b] = next_req++; }
+        admit(ids, rws);
     }
     QTTS_HIP(hipEventRecord(ev1, st));
 
     // ------------------------------------------------------------------ frame pieces
-    const bool trace_l = dbg && dbg->logits, trace_h = dbg && dbg->hidden, trace_c = dbg && dbg->cp_logits;
     if (trace_c) g.trace_cp.ensure((size_t)B * max_new * (G - 1) * Vc * 4);
     if (trace_l) g.trace_logits.ensure((size_t)B * max_new * V * 4);
     if (trace_h) g.trace_hidden.ensure((size_t)B * max_new * H * 4);
@@ -417,7 +489,7 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         a.eos_id = talker ? c.eos : -1;
         // sampling.rs:28-29 via generation.rs:841-842; subtalker: sampling.rs:117
         a.min_new_tokens = talker ? (dbg && dbg->min_new_tokens > 0 ? dbg->min_new_tokens : std::max(0, sp->min_new_tokens)) : 0;
-        a.step = d_step; a.uniforms = g.uniforms.as<float>(); a.codes_base = g.codes.as<unsigned>(); a.row_stride = row_stride;
+        a.step = d_step; a.active = g.active.as<int>(); a.max_steps = max_new; a.uniforms = g.uniforms.as<float>(); a.codes_base = g.codes.as<unsigned>(); a.row_stride = row_stride;
         a.G = G; a.g = gcol; a.eos_step = talker ? g.eos_step.as<int>() : nullptr;
         launch_sample(st, a);
     };
@@ -501,14 +573,14 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         R.split(true);
         EmbedSumArgs ea{};
         ea.codec_emb = m.codec_emb; ea.cp_emb = (const void* const*)m.cp_emb_ptrs.p; ea.edtype = dt;
-        ea.codes_base = g.codes.as<unsigned>(); ea.row_stride = row_stride; ea.step = d_step;
+        ea.codes_base = g.codes.as<unsigned>(); ea.row_stride = row_stride; ea.step = d_step; ea.max_steps = max_new;
         ea.trailing = g.trailing.as<float>(); ea.trailing_len = g.trailing_len.as<int>(); ea.Tt_max = Tt_max;
         ea.tts_pad = tts_pad_row; ea.G = G; ea.H = H; ea.B = B;
         launch_embed_sum_norm(st, dt, ea, m.talker.layers[0].ln1, c.talker.eps, g.ws.x.as<float>(), g.ws.xn.p, g.ws.lo_xn);
-        launch_advance_step(st, d_step);
+        launch_advance_step(st, d_step, g.active.as<int>(), g.eos_step.as<int>(), B, max_new, streaming ? 1 : 0);
     };
     auto talker_step = [&]() {  // generation.rs:1002-1026
-        launch_make_decode_toks(st, g.row_len.as<int>(), g.toks_dec.as<Tok>(), B, c.talker.window);
+        launch_make_decode_toks(st, g.row_len.as<int>(), g.toks_dec.as<Tok>(), B, c.talker.window, g.active.as<int>());
         R.stack(m.talker, B, g.toks_dec.as<Tok>(), g.talker.kv, hid_t, hid_f, true, true, lo_cp);
     };
     auto trace_copy = [&](int step) {
@@ -524,26 +596,32 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     };
 
     // ------------------------------------------------------------------ frame loop
-    std::vector<int> eos((size_t)B, -1);
+    std::vector<int> eos((size_t)B, -1), act_h((size_t)B, 1), step_h((size_t)B, 0);
     int steps_done = 0;
-    auto all_eos = [&]() {
+    auto poll = [&]() {
         QTTS_HIP(hipMemcpyAsync(eos.data(), g.eos_step.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+        if (streaming) {
+            QTTS_HIP(hipMemcpyAsync(act_h.data(), g.active.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+            QTTS_HIP(hipMemcpyAsync(step_h.data(), g.step.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+        }
         QTTS_HIP(hipStreamSynchronize(st));
+    };
+    auto all_eos = [&]() {
+        poll();
         for (int b = 0; b < B; ++b)
             if (eos[(size_t)b] < 0) return false;
         return true;
     };
-    const bool tracing = trace_l || trace_h || trace_c;
-    if (tracing) trace_copy(0);
-    frame_tail(0);
-    steps_done = 1;
-    hipGraph_t graph = nullptr;
-    if (use_graph && !tracing && max_new > 1) {
+    // one graph per call: [talker step, frame tail] for the plain batch (its first tail runs eagerly on the prefill's hidden
+    // state), [frame tail, talker step] for continuous batching, where a row enters between two launches with the hidden state of
+    // its prefill in place
+    auto capture = [&](bool tail_first) {
         if (g.graph_exec) { (void)hipGraphExecDestroy(g.graph_exec); g.graph_exec = nullptr; }
+        hipGraph_t graph = nullptr;
         QTTS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
         try {
-            talker_step();
-            frame_tail(-1);
+            if (tail_first) { frame_tail(-1); talker_step(); }
+            else { talker_step(); frame_tail(-1); }
         } catch (...) {
             hipGraph_t junk = nullptr;
             (void)hipStreamEndCapture(st, &junk);
@@ -553,59 +631,107 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
         QTTS_HIP(hipStreamEndCapture(st, &graph));
         QTTS_HIP(hipGraphInstantiate(&g.graph_exec, graph, nullptr, nullptr, 0));
         QTTS_HIP(hipGraphDestroy(graph));
-    }
-    // first-audio hook: hand the first frames of every row to the caller as soon as they exist
-    bool chunk_sent = !(dbg && dbg->chunk_cb && dbg->first_frames > 0);
-    auto send_chunk = [&](int frames) {
-        chunk_sent = true;
-        if (frames <= 0) return;
-        std::vector<uint32_t> hc((size_t)B * frames * G);
-        QTTS_HIP(hipMemcpy2DAsync(hc.data(), (size_t)frames * G * 4, g.codes.p, (size_t)max_new * G * 4, (size_t)frames * G * 4, B,
-                                  hipMemcpyDeviceToHost, st));
-        QTTS_HIP(hipStreamSynchronize(st));
-        dbg->chunk_cb(dbg->chunk_user, hc.data(), B, frames);
     };
-    bool done = false;
     double launch_host_ms = 0;  // host time inside hipGraphLaunch (the runtime enqueues the graph's nodes one by one)
-    while (steps_done < max_new && !done) {
-        if (!chunk_sent && steps_done >= dbg->first_frames) send_chunk(dbg->first_frames);
-        if (steps_done % EOS_POLL == 0 && all_eos()) { done = true; break; }
-        if (g.graph_exec && use_graph && !tracing) {
-            const auto t0 = std::chrono::steady_clock::now();
-            QTTS_HIP(hipGraphLaunch(g.graph_exec, st));
-            launch_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        } else {
-            talker_step();
-            if (tracing) trace_copy(steps_done);
-            frame_tail(steps_done);
-        }
-        ++steps_done;
-    }
-    QTTS_HIP(hipEventRecord(ev2, st));
-    if (!chunk_sent) send_chunk(std::min(steps_done, dbg->first_frames));
-    all_eos();
-    QTTS_HIP(hipGetLastError());
+    auto launch_graph = [&]() {
+        const auto t0 = std::chrono::steady_clock::now();
+        QTTS_HIP(hipGraphLaunch(g.graph_exec, st));
+        launch_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
 
-    // ------------------------------------------------------------------ results (generation.rs:1125-1193)
-    // The reference stops one step after every row has produced EOS; rows keep generating until then.
-    bool every = true;
-    int last_eos = -1;
-    for (int b = 0; b < B; ++b) {
-        if (eos[(size_t)b] < 0 || eos[(size_t)b] >= steps_done) { every = false; eos[(size_t)b] = -1; }
-        else last_eos = std::max(last_eos, eos[(size_t)b]);
+    if (streaming) {
+        // ---------------------------------------------------------------- continuous batching
+        std::vector<uint32_t> hrow((size_t)max_new * G);
+        const bool graphed = use_graph && max_new > 1;
+        if (graphed) capture(true);
+        int live = B, frames = 0;
+        while (live > 0) {
+            for (int k = 0; k < EOS_POLL; ++k) {
+                if (graphed) launch_graph();
+                else { frame_tail(frames); talker_step(); }
+                ++frames;
+            }
+            poll();
+            std::vector<int> ids, rws;
+            for (int b = 0; b < B; ++b) {
+                const int u = row_req[(size_t)b];
+                if (u < 0 || act_h[(size_t)b] != 0) continue;
+                // the utterance in row b is complete: what a batch of one returns for it (generation.rs:1125-1193)
+                const int e = eos[(size_t)b];
+                int num_steps = std::min(step_h[(size_t)b], max_new);
+                if (e == 0) num_steps = 0;  // ended on its very first token: no frame at all (generation.rs:939,1145-1150)
+                outs[u].num_steps = num_steps;
+                outs[u].effective_len = (e >= 0 && e < num_steps) ? e : num_steps;
+                if (outs[u].codes && num_steps > 0) {
+                    copy_sync(hrow.data(), g.codes.as<unsigned>() + (size_t)b * max_new * G, (size_t)num_steps * G * 4, hipMemcpyDeviceToHost, st);
+                    std::memcpy(outs[u].codes, hrow.data(), (size_t)num_steps * G * 4);
+                }
+                row_req[(size_t)b] = -1;
+                --live;
+                if (next_req < n) { ids.push_back(next_req); rws.push_back(b); row_req[(size_t)b] = next_req++; ++live; }
+            }
+            if (!ids.empty()) admit(ids, rws);
+        }
+        steps_done = frames;
+        QTTS_HIP(hipEventRecord(ev2, st));
+        QTTS_HIP(hipStreamSynchronize(st));
+        QTTS_HIP(hipGetLastError());
+    } else {
+        // ---------------------------------------------------------------- the reference's batch
+        if (tracing) trace_copy(0);
+        frame_tail(0);
+        steps_done = 1;
+        if (use_graph && !tracing && max_new > 1) capture(false);
+        // first-audio hook: hand the first frames of every row to the caller as soon as they exist
+        bool chunk_sent = !(dbg && dbg->chunk_cb && dbg->first_frames > 0);
+        auto send_chunk = [&](int frames) {
+            chunk_sent = true;
+            if (frames <= 0) return;
+            std::vector<uint32_t> hc((size_t)B * frames * G);
+            QTTS_HIP(hipMemcpy2DAsync(hc.data(), (size_t)frames * G * 4, g.codes.p, (size_t)max_new * G * 4, (size_t)frames * G * 4, B,
+                                      hipMemcpyDeviceToHost, st));
+            QTTS_HIP(hipStreamSynchronize(st));
+            dbg->chunk_cb(dbg->chunk_user, hc.data(), B, frames);
+        };
+        bool done = false;
+        while (steps_done < max_new && !done) {
+            if (!chunk_sent && steps_done >= dbg->first_frames) send_chunk(dbg->first_frames);
+            if (steps_done % EOS_POLL == 0 && all_eos()) { done = true; break; }
+            if (g.graph_exec && use_graph && !tracing) {
+                launch_graph();
+            } else {
+                talker_step();
+                if (tracing) trace_copy(steps_done);
+                frame_tail(steps_done);
+            }
+            ++steps_done;
+        }
+        QTTS_HIP(hipEventRecord(ev2, st));
+        if (!chunk_sent) send_chunk(std::min(steps_done, dbg->first_frames));
+        all_eos();
+        QTTS_HIP(hipGetLastError());
+
+        // results (generation.rs:1125-1193).  The reference stops one step after every row has produced EOS; rows keep
+        // generating until then.
+        bool every = true;
+        int last_eos = -1;
+        for (int b = 0; b < B; ++b) {
+            if (eos[(size_t)b] < 0 || eos[(size_t)b] >= steps_done) { every = false; eos[(size_t)b] = -1; }
+            else last_eos = std::max(last_eos, eos[(size_t)b]);
+        }
+        // every row ended on its very first token: the reference returns no frame at all (generation.rs:939,1145-1150)
+        const int num_steps = every ? (last_eos == 0 ? 0 : std::min(steps_done, last_eos + 1)) : steps_done;
+        std::vector<uint32_t> hcodes((size_t)B * max_new * G);
+        copy_sync(hcodes.data(), g.codes.p, hcodes.size() * 4, hipMemcpyDeviceToHost, st);
+        for (int b = 0; b < B; ++b) {
+            outs[b].num_steps = num_steps;
+            outs[b].effective_len = (eos[(size_t)b] >= 0 && eos[(size_t)b] < num_steps) ? eos[(size_t)b] : num_steps;
+            if (outs[b].codes) std::memcpy(outs[b].codes, &hcodes[(size_t)b * max_new * G], (size_t)num_steps * G * 4);
+        }
+        if (trace_l) copy_sync(dbg->logits, g.trace_logits.p, (size_t)B * max_new * V * 4, hipMemcpyDeviceToHost, st);
+        if (trace_h) copy_sync(dbg->hidden, g.trace_hidden.p, (size_t)B * max_new * H * 4, hipMemcpyDeviceToHost, st);
+        if (trace_c) copy_sync(dbg->cp_logits, g.trace_cp.p, (size_t)B * max_new * (G - 1) * Vc * 4, hipMemcpyDeviceToHost, st);
     }
-    // every row ended on its very first token: the reference returns no frame at all (generation.rs:939,1145-1150)
-    const int num_steps = every ? (last_eos == 0 ? 0 : std::min(steps_done, last_eos + 1)) : steps_done;
-    std::vector<uint32_t> hcodes((size_t)B * max_new * G);
-    QTTS_HIP(hipMemcpy(hcodes.data(), g.codes.p, hcodes.size() * 4, hipMemcpyDeviceToHost));
-    for (int b = 0; b < B; ++b) {
-        outs[b].num_steps = num_steps;
-        outs[b].effective_len = (eos[(size_t)b] >= 0 && eos[(size_t)b] < num_steps) ? eos[(size_t)b] : num_steps;
-        if (outs[b].codes) std::memcpy(outs[b].codes, &hcodes[(size_t)b * max_new * G], (size_t)num_steps * G * 4);
-    }
-    if (trace_l) QTTS_HIP(hipMemcpy(dbg->logits, g.trace_logits.p, (size_t)B * max_new * V * 4, hipMemcpyDeviceToHost));
-    if (trace_h) QTTS_HIP(hipMemcpy(dbg->hidden, g.trace_hidden.p, (size_t)B * max_new * H * 4, hipMemcpyDeviceToHost));
-    if (trace_c) QTTS_HIP(hipMemcpy(dbg->cp_logits, g.trace_cp.p, (size_t)B * max_new * (G - 1) * Vc * 4, hipMemcpyDeviceToHost));
     float ms01 = 0, ms12 = 0;
     QTTS_HIP(hipEventElapsedTime(&ms01, ev0, ev1));
     QTTS_HIP(hipEventElapsedTime(&ms12, ev1, ev2));
@@ -617,6 +743,17 @@ void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling
     m.timing[5] = (double)steps_done;
     m.timing[7] = launch_host_ms;
     m.gemm_profile = g.timer.by_shape();
+}
+
+void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling* sp, int max_new, qtts_codes_out* outs,
+                  const qtts_gen_debug* dbg) {
+    generate_impl(m, reqs, n, sp, max_new, outs, dbg, 0);
+}
+
+void run_generate_continuous(Model& m, const qtts_request* reqs, int n, const qtts_sampling* sp, int max_new, int slots,
+                             qtts_codes_out* outs, const qtts_gen_debug* dbg) {
+    QTTS_CHECK(slots >= 1, ERR_BAD_ARG, "generate: at least one row slot");
+    generate_impl(m, reqs, n, sp, max_new, outs, dbg, slots);
 }
 
 }  // namespace qtts

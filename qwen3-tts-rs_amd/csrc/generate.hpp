@@ -8,6 +8,10 @@ namespace qtts {
 void run_generate(Model& m, const qtts_request* reqs, int n, const qtts_sampling* s, int max_new_tokens, qtts_codes_out* outs,
                   const qtts_gen_debug* dbg);
 
+// n utterances through `slots` rows: a finished row's slot is given to the next queued utterance (continuous batching)
+void run_generate_continuous(Model& m, const qtts_request* reqs, int n, const qtts_sampling* s, int max_new_tokens, int slots,
+                             qtts_codes_out* outs, const qtts_gen_debug* dbg);
+
 void finalize_codec(Model& m);
 void run_codec_decode(Model& m, const uint32_t* codes, const int* lens, int B, int T_max, int chunk, int left_ctx, float* wav_out,
                       int64_t wav_stride, int64_t* wav_lens);

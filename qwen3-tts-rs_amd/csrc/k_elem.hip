@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void embed_sum_norm_kernel(EmbedSumArgs a, con
     __shared__ float red[32];
     __shared__ const TE* rowp[64];  // embedding row of every codebook, staged so that the gathers below are independent loads
     const int b = blockIdx.x;
-    const int step = *a.step;
+    const int step = min(a.step[b], a.max_steps - 1);
     const unsigned* codes = a.codes_base + (long)b * a.row_stride + (long)step * a.G;
     if ((int)threadIdx.x < a.G) {
         const int g = threadIdx.x;
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void embed_sum_norm_kernel(EmbedSumArgs a, con
 
 void launch_embed_sum_norm(hipStream_t st, int dtype, const EmbedSumArgs& a, const float* norm_w, float eps, float* resid_out,
                            void* xn, long xn_lo) {
-    QTTS_CHECK(a.B >= 1 && a.H % 8 == 0 && a.G >= 1 && a.G <= 64, ERR_SHAPE, "embed_sum: bad shape");
+    QTTS_CHECK(a.B >= 1 && a.H % 8 == 0 && a.G >= 1 && a.G <= 64 && a.max_steps >= 1, ERR_SHAPE, "embed_sum: bad shape");
     if (a.edtype == BF16 && dtype == BF16) hipLaunchKernelGGL((embed_sum_norm_kernel<bf16_t, bf16_t>), dim3(a.B), dim3(256), 0, st, a, norm_w, eps, resid_out, (bf16_t*)xn, xn_lo);
     else if (a.edtype == F32 && dtype == F32) hipLaunchKernelGGL((embed_sum_norm_kernel<float, float>), dim3(a.B), dim3(256), 0, st, a, norm_w, eps, resid_out, (float*)xn, 0L);
     else throw Error(ERR_BAD_ARG, "embed_sum: embedding and activation dtypes must match");
@@ -319,23 +319,6 @@ void launch_sum_code_rows(hipStream_t st, int edtype, const void* codec_emb, con
     else hipLaunchKernelGGL(sum_code_rows_kernel<float>, dim3(n), dim3(256), 0, st, (const float*)codec_emb, cp_emb, codes, rows, G, H, dst);
 }
 
-template <typename TS, typename TD>
-__global__ __launch_bounds__(256) void gather_codes_kernel(const TS* __restrict__ table, const unsigned* codes_base,
-                                                           long row_stride, const int* step, int G, int g, TD* dst, int H) {
-    const int b = blockIdx.x;
-    const unsigned code = codes_base[(long)b * row_stride + (long)(*step) * G + g];
-    const TS* src = table + (long)code * H;
-    for (int i = threadIdx.x; i < H; i += blockDim.x) dst[(long)b * H + i] = from_f32<TD>(to_f32<TS>(src[i]));
-}
-
-void launch_gather_codes(hipStream_t st, const void* table, int tdtype, const unsigned* codes_base, long row_stride,
-                         const int* step, int G, int g, void* dst, int ddtype, int B, int H) {
-    dim3 gr(B), bl(256);
-    if (tdtype == BF16 && ddtype == BF16) hipLaunchKernelGGL((gather_codes_kernel<bf16_t, bf16_t>), gr, bl, 0, st, (const bf16_t*)table, codes_base, row_stride, step, G, g, (bf16_t*)dst, H);
-    else if (tdtype == F32 && ddtype == F32) hipLaunchKernelGGL((gather_codes_kernel<float, float>), gr, bl, 0, st, (const float*)table, codes_base, row_stride, step, G, g, (float*)dst, H);
-    else if (tdtype == BF16) hipLaunchKernelGGL((gather_codes_kernel<bf16_t, float>), gr, bl, 0, st, (const bf16_t*)table, codes_base, row_stride, step, G, g, (float*)dst, H);
-    else hipLaunchKernelGGL((gather_codes_kernel<float, bf16_t>), gr, bl, 0, st, (const float*)table, codes_base, row_stride, step, G, g, (bf16_t*)dst, H);
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict__ src, T* dst, long n) {
@@ -361,11 +344,13 @@ void launch_copy_rows(hipStream_t st, const void* src, const int* sidx, void* ds
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void make_decode_toks_kernel(int* row_len, Tok* toks, int B, int window) {
+__global__ void make_decode_toks_kernel(int* row_len, Tok* toks, int B, int window, const int* active) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    const int pos = row_len[b];
-    row_len[b] = pos + 1;  // the token decoded this step occupies `pos`
+    const bool live = active == nullptr || active[b] != 0;
+    // a retired row recomputes its last position over and over: it never grows past the pages it owns
+    const int pos = live ? row_len[b] : max(row_len[b] - 1, 0);
+    if (live) row_len[b] = pos + 1;  // the token decoded this step occupies `pos`
     Tok t;
     t.row = b;
     t.pos = pos;
@@ -373,13 +358,20 @@ __global__ void make_decode_toks_kernel(int* row_len, Tok* toks, int B, int wind
     t.ctx_len = pos + 1 - t.ctx_start;
     toks[b] = t;
 }
-void launch_make_decode_toks(hipStream_t st, int* row_len, Tok* toks, int B, int window) {
-    hipLaunchKernelGGL(make_decode_toks_kernel, dim3((B + 63) / 64), dim3(64), 0, st, row_len, toks, B, window);
+void launch_make_decode_toks(hipStream_t st, int* row_len, Tok* toks, int B, int window, const int* active) {
+    hipLaunchKernelGGL(make_decode_toks_kernel, dim3((B + 63) / 64), dim3(64), 0, st, row_len, toks, B, window, active);
 }
 
-__global__ void advance_step_kernel(int* step) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1;
+__global__ void advance_step_kernel(int* step, int* active, const int* eos_step, int B, int max_steps, int retire) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B || active[b] == 0) return;
+    const int s = step[b] + 1;
+    step[b] = s;
+    if (retire && (s >= max_steps || (eos_step[b] >= 0 && s > eos_step[b]))) active[b] = 0;
 }
-void launch_advance_step(hipStream_t st, int* step) { hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(64), 0, st, step); }
+void launch_advance_step(hipStream_t st, int* step, int* active, const int* eos_step, int B, int max_steps, int retire) {
+    QTTS_CHECK(step && active && eos_step && B >= 1 && max_steps >= 1, ERR_BAD_ARG, "advance_step: null argument");
+    hipLaunchKernelGGL(advance_step_kernel, dim3((B + 63) / 64), dim3(64), 0, st, step, active, eos_step, B, max_steps, retire);
+}
 
 }  // namespace qtts

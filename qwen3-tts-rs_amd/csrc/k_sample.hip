@@ -35,7 +35,9 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
     __shared__ float sh_f;
 
     const int b = blockIdx.x, tid = threadIdx.x, V = a.V;
-    const int step = *a.step;
+    // a retired row (active[b] == 0) still runs - the launch covers every slot - on its last frame index, and writes nothing
+    const bool live = a.active == nullptr || a.active[b] != 0;
+    const int step = min(a.step[b], a.max_steps - 1);
     const float* src = a.logits + (long)b * V;
     const int* hc = a.hist_count ? a.hist_count + (long)b * V : nullptr;
     const bool eos_blocked = a.eos_id >= 0 && step < a.min_new_tokens;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
             for (int i = tid * 4; i < H; i += 256 * 4) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
         }
     }
-    if (tid == 0) {
+    if (tid == 0 && live) {
         a.codes_base[(long)b * a.row_stride + (long)step * a.G + a.g] = (unsigned)token;
         if (a.g == 0) {
             if (a.hist_count) a.hist_count[(long)b * V + token] += 1;
@@ -309,7 +311,8 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
 
 void launch_sample(hipStream_t st, const SampleArgs& a) {
     QTTS_CHECK(a.V >= 1 && a.V <= SAMPLE_MAX_V, ERR_SHAPE, "sample: vocabulary larger than the LDS staging buffer");
-    QTTS_CHECK(a.B >= 1 && a.G >= 1 && a.g >= 0 && a.g < a.G && a.row_stride % a.G == 0, ERR_SHAPE, "sample: bad shape");
+    QTTS_CHECK(a.B >= 1 && a.G >= 1 && a.g >= 0 && a.g < a.G && a.row_stride % a.G == 0 && a.max_steps >= 1 &&
+                   (long)a.max_steps * a.G <= a.row_stride, ERR_SHAPE, "sample: bad shape");
     QTTS_CHECK(!a.do_sample || a.uniforms != nullptr, ERR_BAD_ARG, "sample: uniforms required when sampling");
     QTTS_CHECK(a.next_table == nullptr || (a.next_dst != nullptr && a.next_H % 8 == 0 && (a.next_table_bf16 || !a.next_dst_bf16)), ERR_BAD_ARG,
                "sample: bad next-row description");

@@ -123,7 +123,8 @@ struct EmbedSumArgs {
     int edtype;
     const unsigned* codes_base;     // [B][max_steps][G]
     long row_stride;                // max_steps * G
-    const int* step;                // device scalar: current frame index
+    const int* step;                // [B]: every row's frame index
+    int max_steps;                  // frames a row's slice of codes holds (a retired row re-reads its last frame)
     const float* trailing;          // [B][Tt_max][H] f32
     const int* trailing_len;        // [B]
     int Tt_max;
@@ -135,17 +136,16 @@ void launch_embed_sum_norm(hipStream_t st, int dtype, const EmbedSumArgs& a, con
 // fused decode stacks: x (f32 rows) -> xb = T(x * nw) (+ remainder plane), ss_out[row] = sum x^2 (one norm partial tile)
 // x_out (optional) receives a copy of x
 void launch_rows_prep(hipStream_t st, int dtype, const float* x, const float* nw, float* x_out, void* xb, long xb_lo, float* ss_out, int M, int H);
-// code-predictor input rows: dst[b] = table[codes[b][g]] cast to dtype (codes laid out as in EmbedSumArgs)
-void launch_gather_codes(hipStream_t st, const void* table, int tdtype, const unsigned* codes_base, long row_stride,
-                         const int* step, int G, int g, void* dst, int ddtype, int B, int H);
 // ICL prompt rows: dst[rows[i]][:] = codec_emb[codes[i][0]] + sum_g cp_emb[g-1][codes[i][g]]  (f32)
 void launch_sum_code_rows(hipStream_t st, int edtype, const void* codec_emb, const void* const* cp_emb, const int* codes, const int* rows,
                           int n, int G, int H, float* dst);
 void launch_cast_rows(hipStream_t st, const float* src, void* dst, int ddtype, long n);
 // decode-step bookkeeping (device-side so the frame can live in a hipGraph)
-// toks[b] = {b, row_len[b], window start, ctx}; row_len[b] += 1
-void launch_make_decode_toks(hipStream_t st, int* row_len, Tok* toks, int B, int window);
-void launch_advance_step(hipStream_t st, int* step);
+// toks[b] = {b, row_len[b], window start, ctx}; row_len[b] += 1 (rows with active[b] == 0 stay where they are)
+void launch_make_decode_toks(hipStream_t st, int* row_len, Tok* toks, int B, int window, const int* active);
+// step[b] += 1 for active rows.  retire != 0: a row switches itself off once it has produced max_steps frames or the frame with
+// its first EOS (eos_step[b], -1 = none yet) - what a batch of one would have generated
+void launch_advance_step(hipStream_t st, int* step, int* active, const int* eos_step, int B, int max_steps, int retire);
 void launch_copy_rows(hipStream_t st, const void* src, const int* sidx, void* dst, const int* didx, int dtype, int n, int H);
 
 // ---- k_attn.hip
@@ -185,7 +185,9 @@ struct SampleArgs {
     int* hist_count;        // [B][V] occurrences so far (null when rep_penalty == 1)
     int suppress_lo, suppress_hi, eos_id;  // eos_id < 0: none
     int min_new_tokens;
-    const int* step;        // device scalar: frame index (== history length)
+    const int* step;        // [B]: every row's frame index (== its history length)
+    const int* active;      // [B] or null: rows with 0 draw on their last frame index and write nothing
+    int max_steps;          // frames a row's slice of codes / uniforms holds
     const float* uniforms;  // [B][max_steps][G]
     unsigned* codes_base;   // [B][max_steps][G]
     long row_stride;

@@ -206,8 +206,8 @@ void Model::ensure_rope(StackW& s, int max_pos) {
     rope_table_default(s.cfg.d, s.cfg.theta, n, c, sn);
     s.cos.alloc(c.size() * 4);
     s.sin.alloc(sn.size() * 4);
-    QTTS_HIP(hipMemcpy(s.cos.p, c.data(), c.size() * 4, hipMemcpyHostToDevice));
-    QTTS_HIP(hipMemcpy(s.sin.p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+    copy_sync(s.cos.p, c.data(), c.size() * 4, hipMemcpyHostToDevice, ctx->stream);
+    copy_sync(s.sin.p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice, ctx->stream);
     s.max_pos = n;
 }
 

@@ -187,9 +187,9 @@ Batch stage_audio(Model& m, SpeakerState& s, const float* audio, const int* n_sa
     s.audio.ensure((size_t)B * max_samples * 4);
     s.nsamp.ensure((size_t)B * 4);
     s.lens.ensure((size_t)B * 4);
-    QTTS_HIP(hipMemcpy(s.audio.p, audio, (size_t)B * max_samples * 4, hipMemcpyHostToDevice));
-    QTTS_HIP(hipMemcpy(s.nsamp.p, n_samples, (size_t)B * 4, hipMemcpyHostToDevice));
-    QTTS_HIP(hipMemcpy(s.lens.p, b.frames.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+    copy_sync(s.audio.p, audio, (size_t)B * max_samples * 4, hipMemcpyHostToDevice, m.ctx->stream);
+    copy_sync(s.nsamp.p, n_samples, (size_t)B * 4, hipMemcpyHostToDevice, m.ctx->stream);
+    copy_sync(s.lens.p, b.frames.data(), (size_t)B * 4, hipMemcpyHostToDevice, m.ctx->stream);
     (void)m;
     return b;
 }
@@ -312,7 +312,7 @@ void speaker_embed_impl(Model& m, const float* audio, const int* n_samples, int 
         b.frames.assign(n_frames, n_frames + B);
         for (int f : b.frames) b.max_frames = std::max(b.max_frames, f);
         s.lens.ensure((size_t)B * 4);
-        QTTS_HIP(hipMemcpy(s.lens.p, b.frames.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+        copy_sync(s.lens.p, b.frames.data(), (size_t)B * 4, hipMemcpyHostToDevice, m.ctx->stream);
     } else {
         b = stage_audio(m, s, audio, n_samples, B, max_samples);
     }

@@ -270,8 +270,11 @@ class Model:
     # ------------------------------------------------------------------ generation
     def generate(self, requests: Sequence[GenerationRequest], sampling: SamplingConfig, max_new_tokens: int,
                  trace: bool = False, use_graph: bool = True, profile_gemm: bool = False, first_frames: int = 0,
-                 on_first_chunk=None, min_new_tokens: int = 0) -> Output:
+                 on_first_chunk=None, min_new_tokens: int = 0, slots: int = 0) -> Output:
         """ConditionalGeneration::generate (nn/generation.rs:815) over a batch of independent utterances.
+        slots > 0: continuous batching (qtts_generate_continuous) - the utterances go through at most `slots` rows, a finished
+        row's slot is given to the next queued utterance, and every utterance gets the frames a batch of one would produce:
+        Output.codes is padded to the longest one, Output.steps_per_utterance holds each one's own count.
         on_first_chunk(codes (batch, first_frames, groups)) is called once the first `first_frames` frames of every row
         exist, while generation continues afterwards (first-audio hook; the reference has no counterpart).
         min_new_tokens > 0 keeps EOS suppressed for that many frames (fixed-length throughput runs; 0 = the reference's 2)."""
@@ -341,15 +344,21 @@ class Model:
             keep.append(cb)
             dbg.first_frames = int(first_frames)
             dbg.chunk_cb = cb
-        check(self.lib.qtts_generate_ex(self._m, reqs, n, C.byref(sc), max_new_tokens, outs, C.byref(dbg)))
+        if slots > 0:
+            if trace or on_first_chunk is not None:
+                raise QttsError(-1, "continuous batching has no traces and no first-chunk hook")
+            check(self.lib.qtts_generate_continuous(self._m, reqs, n, C.byref(sc), max_new_tokens, int(slots), outs, C.byref(dbg)))
+        else:
+            check(self.lib.qtts_generate_ex(self._m, reqs, n, C.byref(sc), max_new_tokens, outs, C.byref(dbg)))
         if cb_err:
             raise cb_err[0]
         tm = (C.c_double * 8)()
         check(self.lib.qtts_last_timing(self._m, tm, 8))
         self.last_timing = dict(prefill_ms=tm[0], frames_ms=tm[1], gemm_ms=tm[2], gemm_launches=int(tm[3]),
                                 gemm_bytes=tm[4], frames=int(tm[5]), graph_launch_host_ms=tm[7])
-        steps = outs[0].num_steps
+        steps = max(outs[i].num_steps for i in range(n)) if slots > 0 else outs[0].num_steps
         out = Output(codes=codes[:, :steps].copy(), num_steps=steps, effective_lengths=[outs[i].effective_len for i in range(n)])
+        out.steps_per_utterance = [outs[i].num_steps for i in range(n)]
         if trace:
             out.logits = logits[:, :steps]
             out.hidden = hidden[:, :steps]
