@@ -215,6 +215,19 @@ class Oracle:
         self._chk(self.lib.orc_encode_audio(self.h, _vp(a), len(a), valid_q, _vp(codes), C.c_int64(cap), C.byref(T)))
         return codes[:T.value * valid_q].reshape(T.value, valid_q).copy()
 
+    def encode_audio_margins(self, audio: np.ndarray, valid_q: int = 16):
+        """(codes [T][q], gap [T][q], scale [T][q]): gap = second nearest - nearest codebook distance, scale = magnitude of the
+        nearest distance's two terms; gap / scale at float32 rounding level marks a near-tie."""
+        a = np.ascontiguousarray(audio, np.float32)
+        cap = (len(a) // 1920 + 2) * valid_q
+        codes = np.zeros(cap, np.uint32)
+        mg = np.zeros(cap * 2, np.float32)
+        T = C.c_int(0)
+        self._chk(self.lib.orc_encode_audio_margins(self.h, _vp(a), len(a), valid_q, _vp(codes), _vp(mg), C.c_int64(cap), C.byref(T)))
+        n = T.value * valid_q
+        mg = mg[:2 * n].reshape(T.value, valid_q, 2)
+        return codes[:n].reshape(T.value, valid_q).copy(), mg[:, :, 0].copy(), mg[:, :, 1].copy()
+
     def speaker_embed(self, mel: np.ndarray):
         m = np.ascontiguousarray(mel, np.float32)
         out = np.zeros(self.cfg["speaker_encoder_config"]["enc_dim"], np.float32)

@@ -249,6 +249,20 @@ int orc_encode_audio(void* hv, const float* audio, int n, int valid_q, uint32_t*
     ORC_CATCH
 }
 
+// same, plus margins [T][valid_q][2]: (second nearest - nearest distance, magnitude of the nearest distance's terms)
+int orc_encode_audio_margins(void* hv, const float* audio, int n, int valid_q, uint32_t* codes, float* margins, int64_t cap, int* T_out) {
+    ORC_TRY
+    std::vector<uint32_t> c;
+    std::vector<float> mg;
+    int T = 0;
+    encode_audio(((Handle*)hv)->enc, audio, n, valid_q, c, T, &mg);
+    if ((int64_t)c.size() > cap) throw std::runtime_error("oracle: code buffer too small");
+    std::memcpy(codes, c.data(), c.size() * sizeof(uint32_t));
+    std::memcpy(margins, mg.data(), mg.size() * sizeof(float));
+    *T_out = T;
+    ORC_CATCH
+}
+
 int orc_speaker_embed(void* hv, const float* mel, int T, float* out) {
     ORC_TRY
     ((Handle*)hv)->spk.forward(mel, T, out);

@@ -51,7 +51,8 @@ struct SpeakerModel {
 };
 
 // TokenizerV2Encoder::encode (audio/encoder/v2.rs:87-120): 24 kHz waveform -> codes [T][valid_q]; weights under "encoder."
-void encode_audio(const Weights& w, const float* audio, int n, int valid_q, std::vector<uint32_t>& codes, int& T_out);
+void encode_audio(const Weights& w, const float* audio, int n, int valid_q, std::vector<uint32_t>& codes, int& T_out,
+                  std::vector<float>* margins = nullptr);
 
 // audio/mel.rs:81-158 with the default MelSpectrogramConfig; returns [frames][128] (the layout
 // Model::compute_mel_spectrogram hands to the speaker encoder).  n_frames is set.

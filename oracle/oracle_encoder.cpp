@@ -65,7 +65,11 @@ void layer_norm(const float* x, const float* w, const float* b, float* y, int T,
 }  // namespace
 
 // TokenizerV2Encoder::encode (audio/encoder/v2.rs:87-120) for one utterance; codes come out [T][valid_q].
-void encode_audio(const Weights& w, const float* audio, int n, int valid_q, std::vector<uint32_t>& codes, int& T_out) {
+// margins (optional): per (frame, codebook) the distance gap between the nearest and the second nearest entry, and the
+// magnitude |e|^2 / 2 + |x.e| of the winning distance's terms - what a parity test needs to tell a rounding-level near-tie from a
+// wrong code.
+void encode_audio(const Weights& w, const float* audio, int n, int valid_q, std::vector<uint32_t>& codes, int& T_out,
+                  std::vector<float>* margins) {
     const std::string E = "encoder.encoder.layers.";
     // ---- SeaNetEncoder::forward (seanet.rs:153-176)
     std::vector<float> x(audio, audio + n), y;
@@ -181,6 +185,7 @@ void encode_audio(const Weights& w, const float* audio, int n, int valid_q, std:
     for (int c = 0; c < Dm; ++c)
         for (int t = 0; t < T; ++t) rows[(size_t)t * Dm + c] = y[(size_t)c * T + t];
     codes.assign((size_t)T * valid_q, 0);
+    if (margins) margins->assign((size_t)T * valid_q * 2, 0.f);
     int qi = 0;
     for (int grp = 0; grp < 2 && qi < valid_q; ++grp) {
         const std::string P = grp == 0 ? "encoder.quantizer.semantic_residual_vector_quantizer." : "encoder.quantizer.acoustic_residual_vector_quantizer.";
@@ -207,13 +212,19 @@ void encode_audio(const Weights& w, const float* audio, int n, int valid_q, std:
             }
 #pragma omp parallel for schedule(static)
             for (int t = 0; t < T; ++t) {
-                float best = INFINITY;
+                float best = INFINITY, second = INFINITY, best_dot = 0.f;
                 int bi = 0;
                 for (int r = 0; r < bins; ++r) {
-                    const float dist = c2[(size_t)r] - dot(&res[(size_t)t * cd], &emb[(size_t)r * cd], cd);
-                    if (dist < best) { best = dist; bi = r; }  // argmin keeps the first minimum
+                    const float d = dot(&res[(size_t)t * cd], &emb[(size_t)r * cd], cd);
+                    const float dist = c2[(size_t)r] - d;
+                    if (dist < best) { second = best; best = dist; bi = r; best_dot = d; }  // argmin keeps the first minimum
+                    else if (dist < second) second = dist;
                 }
                 codes[(size_t)t * valid_q + qi] = (uint32_t)bi;
+                if (margins) {
+                    (*margins)[((size_t)t * valid_q + qi) * 2] = second - best;
+                    (*margins)[((size_t)t * valid_q + qi) * 2 + 1] = c2[(size_t)bi] + std::fabs(best_dot);
+                }
                 for (int i = 0; i < cd; ++i) res[(size_t)t * cd + i] = res[(size_t)t * cd + i] - emb[(size_t)bi * cd + i];
             }
         }

@@ -23,23 +23,37 @@ def _model(dtype):
     return synthetic_model("T0", dtype=dtype, codec=True, talker=False, encoder=True, round_to_bf16=False)
 
 
+# Integer output: the codes must be the oracle's.  A difference is accepted only where the oracle itself was at a float32
+# near-tie at that (frame, codebook): the gap between its nearest and second nearest codebook distance, relative to the magnitude
+# of the distance's terms, below NEAR_TIE.  (The two encoders sum 20 layers of f32 dot products in different orders; their
+# quantizer inputs agree to ~1e-5 relative, which moves a distance by about that much of its terms' magnitude.)  After an
+# accepted difference the residual of that frame differs, so its later codebooks are not compared.
+NEAR_TIE = 2e-4
+
+
+def _check_codes_against_oracle(enc_oracle, clip, got, label):
+    ref, gap, scale = enc_oracle.encode_audio_margins(clip, 16)
+    assert got.shape == ref.shape == (len(clip) // 1920, 16), label
+    near_ties = 0
+    for t in range(len(ref)):
+        diff = np.nonzero(ref[t] != got[t])[0]
+        if len(diff) == 0:
+            continue
+        q = int(diff[0])
+        rel = float(gap[t, q] / scale[t, q])
+        assert rel < NEAR_TIE, f"{label}: frame {t} codebook {q}: {got[t, q]} vs {ref[t, q]} with a relative distance gap of {rel:.2e}"
+        near_ties += 1
+    assert near_ties <= max(1, len(ref) // 8), f"{label}: {near_ties} near-tie frames of {len(ref)}"
+    return near_ties
+
+
 def test_encoder_codes_match_oracle_f32(enc_oracle):
     m, cfg, ccfg, tmpl = _model("f32")
     try:
         clips = [make_audio(48000, 1), make_audio(1920 * 7 + 333, 2), make_audio(30011, 3)]
         got = m.encode_audio(clips, 16)
-        total = same = 0
-        for a, g in zip(clips, got):
-            ref = enc_oracle.encode_audio(a, 16)
-            assert g.shape == ref.shape == (len(a) // 1920, 16)
-            # an early mismatch changes the residual and with it every later codebook of that frame: compare per frame
-            # up to and including the first difference
-            for t in range(len(ref)):
-                diff = np.nonzero(ref[t] != g[t])[0]
-                n = 16 if len(diff) == 0 else diff[0] + 1
-                total += n
-                same += n if len(diff) == 0 else n - 1
-        assert same / total > 0.99, (same, total)
+        ties = sum(_check_codes_against_oracle(enc_oracle, a, g, f"clip {i}") for i, (a, g) in enumerate(zip(clips, got)))
+        print(f"near-tie frames accepted: {ties}")
         # a clip's codes do not depend on the rest of the batch
         alone = m.encode_audio([clips[1]], 16)[0]
         assert np.array_equal(alone, got[1])
@@ -47,25 +61,26 @@ def test_encoder_codes_match_oracle_f32(enc_oracle):
         m.close()
 
 
-def test_encoder_codes_match_the_independent_mimi_golden():
+def test_encoder_codes_match_the_independent_mimi_golden(enc_oracle):
     """The GPU encoder against codes from transformers' MimiModel on the same weights (tests/golden/make_mimi_golden.py),
-    with no oracle in between; frames are compared up to and including their first difference (near-ties)."""
+    with no oracle in between the two code sets; a frame's first difference must sit on a near-tie of the codebook distances
+    (measured with the oracle's distances on the same weights)."""
     import os
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mimi_encoder_golden.npz"))
     m, cfg, ccfg, tmpl = _model("f32")
     try:
-        total = same = 0
         for name in ("a", "b"):
             clip = make_audio(int(g["clip_" + name + "_len"]), int(g["clip_" + name + "_seed"]))
             ref = g["codes_" + name]
             got = m.encode_audio([clip], 16)[0]
             assert got.shape == ref.shape
+            _, gap, scale = enc_oracle.encode_audio_margins(clip, 16)
             for t in range(len(ref)):
                 diff = np.nonzero(ref[t] != got[t])[0]
-                n = 16 if len(diff) == 0 else diff[0] + 1
-                total += n
-                same += n if len(diff) == 0 else n - 1
-        assert same / total > 0.99, (same, total)
+                if len(diff):
+                    q = int(diff[0])
+                    rel = float(gap[t, q] / scale[t, q])
+                    assert rel < NEAR_TIE, f"clip {name} frame {t} codebook {q}: relative distance gap {rel:.2e}"
     finally:
         m.close()
 
