@@ -372,7 +372,9 @@ bool try_tile(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, int
     const bool long_k = (long)taps * C >= min_k;
     const bool wide_ct = taps == 2 && (long)taps * C >= 1536 && e.N >= 1920;
     const bool big_halo = (size_t)(64 + halo) * C * sizeof(T) > (size_t)64 * 1024;
-    if (off || e.M < min_rows || halo > 128 || (e.M + 255) / 256 > 0x7fffffffL || !(long_k || wide_ct || big_halo)) return false;
+    if (off || e.M < min_rows || halo > 128 || 256 + halo + 8 > CONV_HALO_SLACK || (e.M + 255) / 256 > 0x7fffffffL ||
+        !(long_k || wide_ct || big_halo))
+        return false;
     // channels per phase: as many as keep the tile of 256 rows + halo within 96 KB
     int cph = 0;
     for (int c = C; c >= 64; c -= 64)
@@ -550,6 +552,7 @@ bool launch_unit(hipStream_t st, const T* W1, const T* W2, int wpk, const T* X, 
     const size_t tile_b = (std::max((size_t)(RT + (taps - 1) * dil) * C * sizeof(T), (size_t)RT * (64 * PT + 4) * 4) + 1023) / 1024 * 1024;
     const size_t lds = tile_b + (size_t)RT * C * sizeof(T);
     if (lds > (size_t)76 * 1024) return false;  // at least two blocks per CU
+    if ((long)RT + (long)(taps - 1) * dil + 8 > CONV_HALO_SLACK) return false;
     const long gx = (e.M + RT - 1) / RT;
     if (gx > 0x7fffffffL) return false;
     auto* fn = conv_unit_kernel<T, MT, NT>;
@@ -598,6 +601,7 @@ bool try_halo(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, int
     else if (fits64) { mt = 4; nt = 1; }
     else return false;
     const int rows = 16 * mt;
+    if ((long)rows + (long)halo + 8 > CONV_HALO_SLACK) return false;  // the tile of the last block would read past the callers' slack
     const size_t lds = (std::max((rows + halo) * row_bytes, mt == 8 ? otile128 : otile64) + 1023) / 1024 * 1024;
     if ((e.M + rows - 1) / rows > 0x7fffffffL) return false;
     if (mt == 4 && nt == 4) launch_halo<T, 4, 4>(st, W, wpk, X, K, C, taps, dil, e, lds);
