@@ -328,9 +328,9 @@ def main():
         achieved = bytes_frame * frames_run / elapsed / 1e9
         # HBM-side bytes of one frame from the PMC counters: collected once per round with tools/dev/pmc_frame.sh (rocprofv3 cannot
         # follow a hipGraph, so the passes run the frame eagerly), committed under profiles/ and quoted here when this run is the
-        # configuration they were taken on
+        # configuration they were taken on (bench_data/ travels with the tree to the GPU box, profiles/ does not)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_frame_traffic.json")
+        tpath = os.path.join(ROOT, "bench_data", "r02_frame_traffic.json")   # a copy lives under profiles/
         if os.path.exists(tpath) and args.shape == "S17" and args.batch == 64 and args.dtype == "bf16" and not strong:
             traffic = json.load(open(tpath)).get("traffic_bytes")
         roofline = {"bound": "hbm", "kernel": "decode frame (one hipGraph launch: talker step + code-predictor passes + sampling)",

@@ -6,8 +6,9 @@ set -o pipefail
 out=/root/repo/gpurun_out
 cd /root/repo || exit 1
 bash tools/dev/pmc_frame.sh || exit 1
-python3 tools/pmc_frame_traffic.py $out 12 22 > profiles/r02_frame_traffic.json || exit 2
-cp profiles/r02_frame_traffic.json $out/r02_frame_traffic.json
+mkdir -p bench_data
+python3 tools/pmc_frame_traffic.py $out 12 22 > bench_data/r02_frame_traffic.json || exit 2
+cp bench_data/r02_frame_traffic.json $out/r02_frame_traffic.json
 timeout -k 10 900 python3 bench.py > $out/r02_bench.json 2> $out/r02_bench.err || exit 3
 timeout -k 10 300 python3 bench.py --steps 2 --warmup 1 --pipeline 1 --no-codec --no-cpu-baseline --frames 200 > $out/r02_single_stream.json 2>/dev/null || exit 4
 timeout -k 10 600 python3 bench.py --mode strong --utterances 256 --steps 1 --warmup 1 --no-cpu-baseline > $out/r02_strong_n1.json 2> $out/r02_strong_n1.err || exit 5
