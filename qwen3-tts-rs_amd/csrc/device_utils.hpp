@@ -2,6 +2,19 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Development probe (tools/dev): with QTTS_KERNEL_TS defined, QTTS_TS(i) records the 100 MHz wall clock of the first thread of the
+// launch's first and last block; product builds compile it to nothing.
+#ifdef QTTS_KERNEL_TS
+__device__ unsigned long long g_kernel_ts[2][16];
+#define QTTS_TS(i)                                                                                                        \
+    do {                                                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.y == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))                      \
+            g_kernel_ts[blockIdx.x == 0 ? 0 : 1][i] = wall_clock64();                                                     \
+    } while (0)
+#else
+#define QTTS_TS(i)
+#endif
+
 namespace qtts {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -173,14 +186,49 @@ struct WFragPtr {
     __device__ __forceinline__ const T* chunk(int c) const { return p + (size_t)c * cs; }
 };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions without LDS round trips.  The pairings are those of the __shfl_xor butterflies 32, 16, 8, 4, 2, 1 (every
+// lane adds its partner's value, so the results are the same bit for bit): the gfx950 permlane swaps exchange 32-lane halves and
+// 16-lane rows, DPP row rotations do the rest inside a row (after the step by 8 the values repeat every 8 lanes, so a rotation by
+// 4 reaches the same partner value as lane ^ 4, and so on down).
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+constexpr int DPP_ROW_ROR = 0x120;  // + n: lane i of a 16-lane row reads lane (i + n) % 16
+// a, b <- v: afterwards a holds (lo, lo) and b (hi, hi) of the 32-lane halves; op(a, b) is "own op partner" in every lane for a
+// commutative op.  Written as inline assembly: the instruction updates both registers in place.
+#define QTTS_SWAP_FOLD(NAME, INSN)                                            \
+    template <typename F>                                                     \
+    __device__ __forceinline__ float NAME(float v, F op) {                    \
+        float a = v, b = v;                                                   \
+        asm volatile("s_nop 1\n\t" INSN " %0, %1" : "+v"(a), "+v"(b));        \
+        return op(a, b);                                                      \
+    }
+QTTS_SWAP_FOLD(fold_halves, "v_permlane32_swap_b32")
+QTTS_SWAP_FOLD(fold_rows, "v_permlane16_swap_b32")
+#undef QTTS_SWAP_FOLD
+// sum over each 16-lane row, left in all its lanes (the butterfly 8, 4, 2, 1)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_move<DPP_ROW_ROR + 8>(v);
+    v += dpp_move<DPP_ROW_ROR + 4>(v);
+    v += dpp_move<DPP_ROW_ROR + 2>(v);
+    v += dpp_move<DPP_ROW_ROR + 1>(v);
     return v;
 }
+__device__ __forceinline__ float wave_sum(float v) {
+    const auto add = [](float x, float y) { return x + y; };
+    v = fold_halves(v, add);
+    v = fold_rows(v, add);
+    return row16_sum(v);
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    const auto mx = [](float x, float y) { return fmaxf(x, y); };
+    v = fold_halves(v, mx);
+    v = fold_rows(v, mx);
+    v = fmaxf(v, dpp_move<DPP_ROW_ROR + 8>(v));
+    v = fmaxf(v, dpp_move<DPP_ROW_ROR + 4>(v));
+    v = fmaxf(v, dpp_move<DPP_ROW_ROR + 2>(v));
+    v = fmaxf(v, dpp_move<DPP_ROW_ROR + 1>(v));
     return v;
 }
 

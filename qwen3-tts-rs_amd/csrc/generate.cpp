@@ -534,7 +534,9 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
             sample(g.ws.part.as<float>(), Vc, 1, false, G > 2 ? m.cp_emb[0] : nullptr, inj, in_dt);
             for (int j = 1; j < G - 1; ++j) {  // code_predictor.rs:480-527
                 nt = enter(g.ws.act.p, 0, g.ws.q.as<float>(), B);   // embedding rows: exact in the model dtype, no remainder plane
+                R.uni_len = j + 2;  // every row: position j + 1, keys 0 .. j + 1 (what ct holds for this pass)
                 nt = R.stack_fused(m.cp, B, ct + 2 * B + (size_t)j * B, g.cp.kv, nt, true);
+                R.uni_len = 0;
                 head(j, 0, nt);
                 sample(g.ws.part.as<float>(), Vc, j + 1, false, j + 1 < G - 1 ? m.cp_emb[(size_t)j] : nullptr, inj, in_dt);
             }
@@ -563,7 +565,9 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
                 launch_resid_norm(st, dt, nullptr, g.ws.q.as<float>(), 1, 0, nullptr, nullptr, m.cp.layers[0].ln1, c.cp.eps, g.ws.x.as<float>(), g.ws.xn.p,
                                   nullptr, B, Hc, cxn);
             }
+            R.uni_len = j + 2;
             R.stack(m.cp, B, ct + 2 * B + (size_t)j * B, g.cp.kv, g.ws.xn.p, nullptr, true, true, cxn);
+            R.uni_len = 0;
             R.gemm(m.cp_head[(size_t)j], g.ws.xn.p, B, Vc, Hc, 1, Hc, cxn);
             trace_cp(j);
             sample(g.ws.part.as<float>(), Vc, j + 1, false, j + 1 < G - 1 ? m.cp_emb[(size_t)j] : nullptr, inj, in_dt);

@@ -9,6 +9,8 @@
 #include "device_utils.hpp"
 #include "kernels.hpp"
 
+#include <cstdlib>
+
 namespace qtts {
 
 template <typename T>
@@ -159,20 +161,37 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     }
 }
 
+// sum over the LPK lanes that share a key, left in all of them (butterfly LPK/2 .. 1)
+template <int LPK>
+__device__ __forceinline__ float key_group_sum(float s) {
+    if constexpr (LPK == 16) {
+        return row16_sum(s);
+    } else {
+#pragma unroll
+        for (int off = LPK / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        return s;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Decode-step variant: the token's own q/k/v post-processing (split-K combine, bias, per-head RMSNorm, RoPE, KV
 // append) happens inside the attention block, so one launch replaces qkv_post + attention.  Valid only when a
 // token's newest key is its own position and no other token of the launch attends to it (decode steps, the code
 // predictor's single-token passes); prefill chunks use the two-kernel path.
-template <typename T, int D, int REP>
+template <typename T, int D, int REP, int NG>
 __global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KVView kv, float scale, T* out, long out_lo) {
     constexpr int LPK = D / 8, KPW = 64 / LPK, HALF = D / 2;
-    __shared__ float sm[4][REP][LPK][10];
+    constexpr int NP = 4 * KPW;  // partial results of a block: one per (wave, lane group)
+    __shared__ float po[NP][REP][D];         // unnormalised weighted sums of V
+    __shared__ float pm[NP][REP], pl[NP][REP], pa[NP][REP], pL[REP];
     __shared__ float qs[REP][D];
     __shared__ float kown[D], vown[D];
+    QTTS_TS(0);
     const int m = blockIdx.x, g = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const Tok t = a.toks[m];
+    // a launch whose tokens all sit at one position (the code predictor's passes) describes them in the arguments: one
+    // dependent load less in front of the K/V rows
+    const Tok t = a.uni_len > 0 ? Tok{m, a.uni_len - 1, 0, a.uni_len} : a.toks[m];
     const int ncol = (a.nh + 2 * a.nkv) * D;
     // The key loop is software-pipelined by hand: a fetch covers NG groups of KPW keys per wave, and the K/V rows (with the
     // page-table entries in front of them) of the next fetch are in flight while the current one goes through the online softmax.
@@ -180,7 +199,6 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KV
     // batches in flight the extra resident blocks are worth more than the deeper prefetch.
     // The first fetch is issued before phase 1, so that the cached rows travel while the token's own q/k/v are put together;
     // the newest key is not in the cache yet and is patched in from LDS (own_key) after the barrier.
-    constexpr int NG = 1;
     const int gi = lane / LPK, li = lane % LPK;
     auto fetch = [&](int base, float(&kf)[NG][8], float(&vf)[NG][8]) {
 #pragma unroll
@@ -245,7 +263,9 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KV
             }
         }
     }
+    QTTS_TS(1);
     __syncthreads();
+    QTTS_TS(2);
     // ---- phase 2: online-softmax attention; the newest key comes from LDS, the rest from the cache
     float qv[REP][8], o[REP][8], mx[REP], l[REP];
 #pragma unroll
@@ -259,21 +279,24 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KV
 #pragma unroll
         for (int n = 0; n < NG; ++n) {
             const bool valid = base + n * KPW + gi < t.ctx_len;
+            float vz[8];  // a padding lane's row is whatever the cache holds: it must not meet its zero weight as inf or NaN
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vz[e] = valid ? vf[n][e] : 0.f;
 #pragma unroll
             for (int h = 0; h < REP; ++h) {
                 float s = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s += qv[h][e] * kf[n][e];
-#pragma unroll
-                for (int off = LPK / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+                s = key_group_sum<LPK>(s);
                 s = valid ? s * scale : -INFINITY;
-                const float mn = fmaxf(mx[h], s);
-                const float alpha = expf(mx[h] - mn);
-                const float p = expf(s - mn);
+                // online softmax step: of exp(mx - mn) and exp(s - mn) one is exp(0) = 1, so one exponential serves both
+                const bool up = s > mx[h];
+                const float ex = expf(up ? mx[h] - s : s - mx[h]);
+                const float alpha = up ? ex : 1.0f, p = up ? 1.0f : ex;
                 l[h] = l[h] * alpha + p;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[h][e] = o[h][e] * alpha + (valid ? p * vf[n][e] : 0.f);  // a padding lane's row is whatever the cache holds
-                mx[h] = mn;
+                for (int e = 0; e < 8; ++e) o[h][e] = o[h][e] * alpha + p * vz[e];
+                mx[h] = up ? s : mx[h];
             }
         }
     };
@@ -292,54 +315,76 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KV
             base += STEP;
         }
     }
+    QTTS_TS(3);
+    // ---- merge of the NP partial softmaxes (running maximum m, sum l, weighted V sum o): every lane group hands its own over
+    // through LDS; REP * NP threads turn the maxima into weights a = exp(m - M) and the total L = sum a l; then one thread per
+    // output element adds the weighted partials in partial order.
+    {
+        const int part = wave * KPW + gi;
 #pragma unroll
-    for (int h = 0; h < REP; ++h) {
-#pragma unroll
-        for (int off = LPK; off < 64; off <<= 1) {
-            const float mo = __shfl_xor(mx[h], off, 64), lo = __shfl_xor(l[h], off, 64);
-            const float mn = fmaxf(mx[h], mo);
-            const float a1 = expf(mx[h] - mn), a2 = expf(mo - mn);
-            l[h] = l[h] * a1 + lo * a2;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[h][e] = o[h][e] * a1 + __shfl_xor(o[h][e], off, 64) * a2;
-            mx[h] = mn;
+        for (int h = 0; h < REP; ++h) {
+            *reinterpret_cast<float4*>(&po[part][h][li * 8]) = make_float4(o[h][0], o[h][1], o[h][2], o[h][3]);
+            *reinterpret_cast<float4*>(&po[part][h][li * 8 + 4]) = make_float4(o[h][4], o[h][5], o[h][6], o[h][7]);
+            if (li == 0) {
+                pm[part][h] = mx[h];
+                pl[part][h] = l[h];
+            }
         }
-        if (gi == 0) {
-            sm[wave][h][li][0] = mx[h];
-            sm[wave][h][li][1] = l[h];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sm[wave][h][li][2 + e] = o[h][e];
+    }
+    QTTS_TS(4);
+    __syncthreads();
+    QTTS_TS(5);
+    if (threadIdx.x < REP * NP) {
+        const int h = threadIdx.x / NP, part = threadIdx.x % NP;
+        const float m = pm[part][h];
+        float M, L;
+        if constexpr (NP == 16) {  // the partials of a head sit in one 16-lane row
+            M = m;
+            M = fmaxf(M, dpp_move<DPP_ROW_ROR + 8>(M));
+            M = fmaxf(M, dpp_move<DPP_ROW_ROR + 4>(M));
+            M = fmaxf(M, dpp_move<DPP_ROW_ROR + 2>(M));
+            M = fmaxf(M, dpp_move<DPP_ROW_ROR + 1>(M));
+            const float aw = expf(m - M);
+            pa[part][h] = aw;
+            L = row16_sum(aw * pl[part][h]);
+        } else {
+            M = pm[0][h];
+            for (int q = 1; q < NP; ++q) M = fmaxf(M, pm[q][h]);
+            pa[part][h] = expf(m - M);
+            L = 0.f;
+            for (int q = 0; q < NP; ++q) L += expf(pm[q][h] - M) * pl[q][h];
         }
+        if (part == 0) pL[h] = L;
     }
     __syncthreads();
-    if (threadIdx.x < REP * LPK) {
-        const int h = threadIdx.x / LPK, j = threadIdx.x % LPK;
-        float mn = sm[0][h][j][0];
-        for (int w = 1; w < 4; ++w) mn = fmaxf(mn, sm[w][h][j][0]);
-        float lt = 0.f, ot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int w = 0; w < 4; ++w) {
-            const float aw = expf(sm[w][h][j][0] - mn);
-            lt += sm[w][h][j][1] * aw;
+    for (int idx = threadIdx.x; idx < REP * D; idx += 256) {
+        const int h = idx / D, dd = idx % D;
+        float acc = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ot[e] += sm[w][h][j][2 + e] * aw;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ot[e] = ot[e] / lt;
-        store8_split<T>(out + ((long)m * a.nh + (long)g * REP + h) * D + j * 8, out_lo, ot);
+        for (int q = 0; q < NP; ++q) acc += pa[q][h] * po[q][h][dd];
+        store_split<T>(out + ((long)m * a.nh + (long)g * REP + h) * D + dd, out_lo, acc / pL[h]);
     }
+    QTTS_TS(6);
 }
 
-template <typename T, int D>
-static void launch_attn_decode_rep(hipStream_t st, const QkvPostArgs& a, const KVView& kv, float scale, T* out, long out_lo) {
+template <typename T, int D, int NG>
+static void launch_attn_decode_ng(hipStream_t st, const QkvPostArgs& a, const KVView& kv, float scale, T* out, long out_lo) {
     const int rep = a.nh / kv.nkv;
     dim3 grid(a.M, kv.nkv), block(256);
     switch (rep) {
-        case 1: hipLaunchKernelGGL((attention_decode_kernel<T, D, 1>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
-        case 2: hipLaunchKernelGGL((attention_decode_kernel<T, D, 2>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
-        case 4: hipLaunchKernelGGL((attention_decode_kernel<T, D, 4>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
-        case 8: hipLaunchKernelGGL((attention_decode_kernel<T, D, 8>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
+        case 1: hipLaunchKernelGGL((attention_decode_kernel<T, D, 1, NG>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
+        case 2: hipLaunchKernelGGL((attention_decode_kernel<T, D, 2, NG>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
+        case 4: hipLaunchKernelGGL((attention_decode_kernel<T, D, 4, NG>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
+        case 8: hipLaunchKernelGGL((attention_decode_kernel<T, D, 8, NG>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
         default: throw Error(ERR_SHAPE, "attention: heads per kv head must be 1, 2, 4 or 8");
     }
+}
+template <typename T, int D>
+static void launch_attn_decode_rep(hipStream_t st, const QkvPostArgs& a, const KVView& kv, float scale, T* out, long out_lo) {
+    static const int ng = getenv("QTTS_ATTN_NG") ? atoi(getenv("QTTS_ATTN_NG")) : 1;
+    if (ng == 4 && a.nh / kv.nkv <= 2) launch_attn_decode_ng<T, D, 4>(st, a, kv, scale, out, out_lo);
+    else if (ng >= 2 && a.nh / kv.nkv <= 2) launch_attn_decode_ng<T, D, 2>(st, a, kv, scale, out, out_lo);
+    else launch_attn_decode_ng<T, D, 1>(st, a, kv, scale, out, out_lo);
 }
 
 void launch_attention_decode(hipStream_t st, int dtype, const QkvPostArgs& a, const KVView& kv, float scale, void* out, long out_lo) {

@@ -396,6 +396,15 @@ __global__ __launch_bounds__(64 * KS_WAVES) void gemm_k_split_kernel(const bf16_
     const bool shared_w = gridDim.y > 1;
     const int s0 = unit_slot(r, g, 0), s1 = unit_slot(r, g, 1);
     f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // the first wave finishes the tile; what its epilogue reads (bias, residual, norm weight) is requested now, so that the
+    // memory round trip runs beside the K loop instead of after it
+    const int em = row0 + (lane & 15), en = n0 + 4 * (lane >> 4);
+    float4 pre_b = make_float4(0.f, 0.f, 0.f, 0.f), pre_r = pre_b, pre_w = pre_b;
+    if (wave == 0) {
+        if (e.bias) pre_b = *reinterpret_cast<const float4*>(e.bias + en);
+        if (e.resid) pre_r = *reinterpret_cast<const float4*>(e.resid + (size_t)em * N + en);
+        pre_w = *reinterpret_cast<const float4*>(e.nw + en);
+    }
 
     for (int c0 = ca; c0 < cb; c0 += gcap) {
         if (c0 != ca) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the previous group's LDS reads are done before its units are overwritten
@@ -434,18 +443,16 @@ __global__ __launch_bounds__(64 * KS_WAVES) void gemm_k_split_kernel(const bf16_
         f32x4_t v = red[l];
 #pragma unroll
         for (int w = 1; w < NW; ++w) v += red[w * 64 + l];
-        const int m = row0 + (l & 15), n = n0 + 4 * (l >> 4);
+        const int m = em, n = en;
         float x[4] = {v[0], v[1], v[2], v[3]};
         if (e.bias) {
-            const float4 b4 = *reinterpret_cast<const float4*>(e.bias + n);
-            x[0] += b4.x; x[1] += b4.y; x[2] += b4.z; x[3] += b4.w;
+            x[0] += pre_b.x; x[1] += pre_b.y; x[2] += pre_b.z; x[3] += pre_b.w;
         }
         if (e.resid) {
-            const float4 r4 = *reinterpret_cast<const float4*>(e.resid + (size_t)m * N + n);
-            x[0] = r4.x + x[0]; x[1] = r4.y + x[1]; x[2] = r4.z + x[2]; x[3] = r4.w + x[3];
+            x[0] = pre_r.x + x[0]; x[1] = pre_r.y + x[1]; x[2] = pre_r.z + x[2]; x[3] = pre_r.w + x[3];
         }
         *reinterpret_cast<float4*>(e.x_out + (size_t)m * N + n) = make_float4(x[0], x[1], x[2], x[3]);
-        const float4 w4 = *reinterpret_cast<const float4*>(e.nw + n);
+        const float4 w4 = pre_w;
         bf16_t* xb = (bf16_t*)e.xb_out + (size_t)m * N + n;
         store_split<bf16_t>(xb, e.xb_lo, x[0] * w4.x);
         store_split<bf16_t>(xb + 1, e.xb_lo, x[1] * w4.y);
@@ -453,8 +460,9 @@ __global__ __launch_bounds__(64 * KS_WAVES) void gemm_k_split_kernel(const bf16_
         store_split<bf16_t>(xb + 3, e.xb_lo, x[3] * w4.w);
         // the row's sum of squares over this block's 16 columns: the four lanes 16 apart hold them
         float ss = x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
-        ss += __shfl_xor(ss, 16, 64);
-        ss += __shfl_xor(ss, 32, 64);
+        const auto add = [](float x0, float x1) { return x0 + x1; };
+        ss = fold_rows(ss, add);
+        ss = fold_halves(ss, add);
         if ((l >> 4) == 0) e.ss_out[(long)tile * e.ss_ld + m] = ss;
     }
 }
@@ -583,7 +591,9 @@ void launch_gemm_k_split(hipStream_t st, WMat Wm, const void* X, int ldx, long x
     dim3 grid(N / 16, rows / 16);
     const int planes = x_lo ? 2 : 1;
     const int per_wave = (K / CHUNK + KS_WAVES - 1) / KS_WAVES;          // chunks of the longest wave slice
-    const int gcap = std::max(1, std::min(KS_GROUP / planes, per_wave));
+    static const int group_env = getenv("QTTS_KS_GROUP") ? atoi(getenv("QTTS_KS_GROUP")) : KS_GROUP;
+    const int group = std::max(planes, std::min(KS_GROUP, group_env));
+    const int gcap = std::max(1, std::min(group / planes, per_wave));
     const size_t lds = (size_t)KS_WAVES * 64 * 16 + (size_t)KS_WAVES * planes * gcap * 2048;
     if (x_lo) {
         if (lds > 64 * 1024) raise_lds_limit((const void*)gemm_k_split_kernel<true>, 38);

@@ -163,6 +163,7 @@ struct QkvPostArgs {
     const Tok* toks;
     int M, nh, nkv, d, layer;
     float* q_out;        // [Mpad][nh d] f32
+    int uni_len = 0;     // decode launches only: > 0 = every token m is Tok{m, uni_len - 1, 0, uni_len}; toks is not read
 };
 void launch_qkv_post(hipStream_t st, int dtype, const QkvPostArgs& a, const KVView& kv);
 // softmax(q k^T * scale over the token's key range) v  -> out [Mpad][nh d] in dtype

@@ -75,6 +75,9 @@ struct GemmTimer {
 };
 
 struct Runner {
+    // decode launches whose tokens all sit at one position (row m = token m, keys 0 .. uni_len - 1) say so here: the attention
+    // kernel then takes the description from its arguments instead of loading it (0 = read the token table)
+    int uni_len = 0;
     Model& m;
     Workspace& g;
     GemmTimer* timer;
@@ -153,7 +156,7 @@ struct Runner {
         qa.part = g.part.as<float>(); qa.KS = ks; qa.ks_stride = kstride(M, nqkv); qa.bias = fk ? nullptr : w.qkv_bias;
         qa.q_norm = w.q_norm; qa.k_norm = w.k_norm; qa.eps = c.eps; qa.cos = s.cos.as<float>(); qa.sin = s.sin.as<float>();
         qa.rope_mode = 0; qa.toks = toks; qa.M = M; qa.nh = c.nh; qa.nkv = c.nkv; qa.d = c.d; qa.layer = kv_layer;
-        qa.q_out = g.q.as<float>();
+        qa.q_out = g.q.as<float>(); qa.uni_len = decode ? uni_len : 0;
         if (decode) {
             launch_attention_decode(st, dt, qa, kv, (float)std::pow((double)c.d, -0.5), g.attn.p, lo_attn);
         } else {
@@ -248,7 +251,7 @@ struct Runner {
         qa.part = g.part.as<float>(); qa.KS = 1; qa.ks_stride = 0; qa.bias = nullptr;
         qa.q_norm = w.q_norm; qa.k_norm = w.k_norm; qa.eps = c.eps; qa.cos = s.cos.as<float>(); qa.sin = s.sin.as<float>();
         qa.rope_mode = 0; qa.toks = toks; qa.M = M; qa.nh = c.nh; qa.nkv = c.nkv; qa.d = c.d; qa.layer = kv_layer;
-        qa.q_out = g.q.as<float>();
+        qa.q_out = g.q.as<float>(); qa.uni_len = decode ? uni_len : 0;
         const float scale = (float)std::pow((double)c.d, -0.5);
         if (decode) {
             launch_attention_decode(st, dt, qa, kv, scale, g.attn.p, lo_attn);
