@@ -271,10 +271,10 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
     R.split(true);  // the runner's copy of the plane offsets follows the allocation
     // code predictor as five launches per layer (bf16, hidden <= 1024, single-plane activations)
     const bool fused_cp = Runner::stack_fusable(m, m.cp) && !split_cp && Vc % 64 == 0 && H % 64 == 0;
-    if (fused_cp) {
+    if (fused_cp || dt == BF16) {  // (the talker's decode steps use ssB between the o projection and gate|up)
         g.ws.ss_ld = (long)fused_rows(2 * B) + 64;
-        g.ws.ssA.ensure((size_t)(Hc / 16 + 1) * g.ws.ss_ld * 4);
-        g.ws.ssB.ensure((size_t)(Hc / 16 + 1) * g.ws.ss_ld * 4);
+        g.ws.ssA.ensure((size_t)(std::max(H, Hc) / 16 + 1) * g.ws.ss_ld * 4);
+        g.ws.ssB.ensure((size_t)(std::max(H, Hc) / 16 + 1) * g.ws.ss_ld * 4);
     }
     // up to GEMM_MAX_KS split-K slabs for the small-M kernels (at most 512 rows); the large-M kernel writes one [rows][N] matrix
     g.ws.part.ensure(std::max(rows, (size_t)GEMM_MAX_KS * std::min<size_t>(rows, 512)) * (size_t)Nmax * 4);

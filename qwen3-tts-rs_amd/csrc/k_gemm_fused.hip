@@ -161,6 +161,7 @@ template <int MT, int MODE, int KH, bool LO>
 __global__ __launch_bounds__(256 * KH) void gemm_full_k_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, int N, int K, int ldx,
                                                                long x_lo, int wpk, FusedEpi e) {
     constexpr int MAXC = 16, PL = LO ? 2 : 1;
+    QTTS_TS(0);
     extern __shared__ uint4 xs[];  // [PL][nC][MT] units of 2 KiB, then 4 x 64 partial sums of squares, then (KH == 2) 4 x MT partial tiles
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
@@ -192,8 +193,11 @@ __global__ __launch_bounds__(256 * KH) void gemm_full_k_kernel(const bf16_t* __r
     f32x4_t acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    QTTS_TS(1);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's LDS DMA has landed before it signals the barrier
+    QTTS_TS(2);
     __syncthreads();
+    QTTS_TS(3);
     const int s0 = unit_slot(r, g, 0), s1 = unit_slot(r, g, 1);
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
@@ -206,17 +210,22 @@ __global__ __launch_bounds__(256 * KH) void gemm_full_k_kernel(const bf16_t* __r
             }
         }
     }
-    if constexpr (KH == 2) {  // the upper K half hands its tiles to the lower one
-        if (kh == 1) {
+    QTTS_TS(4);
+    if constexpr (KH > 1) {  // the upper K slices hand their tiles to the lowest one, which adds them in slice order
+        if (kh > 0) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) red[(ct * MT + i) * 64 + lane] = acc[i];
+            for (int i = 0; i < MT; ++i) red[(((kh - 1) * 4 + ct) * MT + i) * 64 + lane] = acc[i];
         }
         __syncthreads();
-        if (kh == 1) return;
+        if (kh > 0) return;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) acc[i] += red[(ct * MT + i) * 64 + lane];
+        for (int q = 0; q < KH - 1; ++q)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i] += red[((q * 4 + ct) * MT + i) * 64 + lane];
     }
+    QTTS_TS(5);
     finished_tile_epilogue<MT, MODE>(acc, e, ssq, row0, n0, N, r, g);
+    QTTS_TS(6);
 }
 
 // ------------------------------------------------------------------------------------------------ stream
@@ -382,6 +391,7 @@ template <bool LO>
 __global__ __launch_bounds__(64 * KS_WAVES) void gemm_k_split_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, int N, int K,
                                                                      int ldx, long x_lo, int wpk, int gcap, FusedEpi e) {
     constexpr int NW = KS_WAVES, PL = LO ? 2 : 1, G = KS_GROUP / PL;
+    QTTS_TS(0);
     extern __shared__ uint4 ksm[];  // red[NW][64] partial tiles, then every wave's own X units [NW][PL][gcap][128]
     f32x4_t* red = reinterpret_cast<f32x4_t*>(ksm);
     uint4* xw = ksm + NW * 64 + (size_t)(threadIdx.x >> 6) * PL * gcap * 128;
@@ -435,8 +445,10 @@ __global__ __launch_bounds__(64 * KS_WAVES) void gemm_k_split_kernel(const bf16_
             }
         }
     }
+    QTTS_TS(1);
     red[wave * 64 + lane] = acc;
     __syncthreads();
+    QTTS_TS(2);
     // lane l of the first wave: row l & 15, columns n0 + 4 (l >> 4) .. + 3; partial tiles are added in wave order
     if (wave == 0) {
         const int l = lane;
@@ -465,6 +477,7 @@ __global__ __launch_bounds__(64 * KS_WAVES) void gemm_k_split_kernel(const bf16_
         ss = fold_halves(ss, add);
         if ((l >> 4) == 0) e.ss_out[(long)tile * e.ss_ld + m] = ss;
     }
+    QTTS_TS(3);
 }
 
 }  // namespace
@@ -476,10 +489,10 @@ int fused_rows(int M) { return M <= 16 ? 16 : (M <= 32 ? 32 : (M + 63) / 64 * 64
 // more than 64 KB of dynamic LDS needs the limit raised once per kernel (per device: the attribute lives with the loaded code object)
 static void raise_lds_limit(const void* fn, int slot) {
     static std::mutex mu;
-    static bool raised[64][40] = {};
+    static bool raised[64][64] = {};
     int dev = 0;
     QTTS_HIP(hipGetDevice(&dev));
-    QTTS_CHECK(dev >= 0 && dev < 64 && slot >= 0 && slot < 40, ERR_STATE, "fused gemm: device ordinal out of range");
+    QTTS_CHECK(dev >= 0 && dev < 64 && slot >= 0 && slot < 64, ERR_STATE, "fused gemm: device ordinal out of range");
     std::lock_guard<std::mutex> lock(mu);
     if (!raised[dev][slot]) {
         QTTS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -487,28 +500,43 @@ static void raise_lds_limit(const void* fn, int slot) {
     }
 }
 
+// K slices taken by separate waves of a block (4 waves per slice).  Measured at 64 rows, K = 1024 (us per launch, one / two
+// slices, stand-alone): gate|up N = 6144 8.95 / 7.26, q|k|v N = 4096 6.07 / 5.64, a 2048-wide head 5.83 / 5.38; inside the decode
+// frame the wide launch keeps its gain (9.46 / 8.57) and the narrower ones lose it (6.67 / 7.00), so two slices are taken from
+// N = 6144 on.  Four slices (1024 threads: the weight fragments no longer fit the registers) 12.7 and worse.
+// QTTS_FULL_K_SLICES: 1 = one slice whenever K <= 1024, 2 = two slices whenever K >= 1024.
+static int full_k_slices(int K, int N) {
+    static const int forced = getenv("QTTS_FULL_K_SLICES") ? atoi(getenv("QTTS_FULL_K_SLICES")) : 0;
+    if (K % (2 * CHUNK) != 0) return 1;
+    if (K > 1024) return 2;  // a wave holds at most 16 chunks of weights
+    if (K < 1024 || forced == 1) return 1;
+    return forced == 2 || N >= 6144 ? 2 : 1;
+}
 constexpr size_t FULL_K_LDS_MAX = 150 * 1024;  // X tile + partial sums + hand-over tiles of one block
 static size_t full_k_lds(int K, int mt, int planes, int kh) {
-    return (size_t)planes * (K / CHUNK) * mt * 2048 + 4 * 64 * 4 + (kh == 2 ? (size_t)4 * mt * 64 * 16 : 0);
+    return (size_t)planes * (K / CHUNK) * mt * 2048 + 4 * 64 * 4 + (size_t)(kh - 1) * 4 * mt * 64 * 16;
 }
 
 template <int MT, int MODE, int KH, bool LO>
 static void launch_full_k_inst(hipStream_t st, const bf16_t* W, int wpk, const bf16_t* X, long x_lo, int rows, int N, int K, int ldx, const FusedEpi& e) {
     const size_t lds = full_k_lds(K, MT, LO ? 2 : 1, KH);
     dim3 grid(N / 64, rows / (16 * MT));
-    if (lds > 64 * 1024) raise_lds_limit((const void*)gemm_full_k_kernel<MT, MODE, KH, LO>, (MT == 4 ? 0 : (MT == 2 ? 1 : 2)) * 8 + MODE * 4 + (KH - 1) * 2 + (LO ? 1 : 0));
+    if (lds > 64 * 1024)
+        raise_lds_limit((const void*)gemm_full_k_kernel<MT, MODE, KH, LO>, ((MT == 4 ? 0 : (MT == 2 ? 1 : 2)) * 2 + MODE) * 4 + (KH - 1) * 2 + (LO ? 1 : 0));
     hipLaunchKernelGGL((gemm_full_k_kernel<MT, MODE, KH, LO>), grid, dim3(256 * KH), lds, st, W, X, N, K, ldx, x_lo, wpk, e);
 }
 template <int MT, int MODE>
 static void launch_full_k_mode(hipStream_t st, const bf16_t* W, int wpk, const bf16_t* X, long x_lo, int rows, int N, int K, int ldx, const FusedEpi& e) {
-    const bool kh2 = K > 1024;
-    if (kh2 && x_lo) launch_full_k_inst<MT, MODE, 2, true>(st, W, wpk, X, x_lo, rows, N, K, ldx, e);
-    else if (kh2) launch_full_k_inst<MT, MODE, 2, false>(st, W, wpk, X, 0, rows, N, K, ldx, e);
-    else if (x_lo) launch_full_k_inst<MT, MODE, 1, true>(st, W, wpk, X, x_lo, rows, N, K, ldx, e);
-    else launch_full_k_inst<MT, MODE, 1, false>(st, W, wpk, X, 0, rows, N, K, ldx, e);
+    const int kh = full_k_slices(K, N);
+#define QTTS_FULL_K_KH(KHV)                                                                          \
+    if (x_lo) launch_full_k_inst<MT, MODE, KHV, true>(st, W, wpk, X, x_lo, rows, N, K, ldx, e);      \
+    else launch_full_k_inst<MT, MODE, KHV, false>(st, W, wpk, X, 0, rows, N, K, ldx, e)
+    if (kh == 2) { QTTS_FULL_K_KH(2); }
+    else { QTTS_FULL_K_KH(1); }
+#undef QTTS_FULL_K_KH
 }
 
-bool full_k_fits(int K, bool lo) { return K % CHUNK == 0 && K <= 2048 && (K <= 1024 || K % (2 * CHUNK) == 0) && full_k_lds(K, 1, lo ? 2 : 1, K > 1024 ? 2 : 1) <= FULL_K_LDS_MAX; }
+bool full_k_fits(int K, bool lo) { return K % CHUNK == 0 && K <= 2048 && (K <= 1024 || K % (2 * CHUNK) == 0) && full_k_lds(K, 1, lo ? 2 : 1, 2) <= FULL_K_LDS_MAX; }
 
 void launch_gemm_full_k(hipStream_t st, WMat Wm, const void* X, int ldx, long x_lo, int M, int N, int K, const FusedEpi& e) {
     QTTS_CHECK(M >= 1 && N % 64 == 0 && full_k_fits(K, x_lo != 0), ERR_SHAPE, "gemm_full_k: N must be a multiple of 64 and a 16-row X tile must fit LDS");
@@ -520,7 +548,7 @@ void launch_gemm_full_k(hipStream_t st, WMat Wm, const void* X, int ldx, long x_
     const bf16_t* w = (const bf16_t*)Wm.p;
     const bf16_t* x = (const bf16_t*)X;
     const int wpk = Wm.packed ? 1 : 0;
-    const int planes = x_lo ? 2 : 1, kh = K > 1024 ? 2 : 1;
+    const int planes = x_lo ? 2 : 1, kh = full_k_slices(K, N);
     // row tiles per block: the most that fits LDS and still gives about 192 blocks (a 64-row launch of 64 column blocks
     // becomes 256 blocks of 16 rows)
     int mt = rows >= 64 ? 4 : rows / 16;
@@ -555,7 +583,7 @@ static void launch_stream_np(hipStream_t st, const bf16_t* W, int wpk, const bf1
 template <int MODE, bool LO>
 static void launch_stream_inst(hipStream_t st, const bf16_t* W, int wpk, const bf16_t* X, long x_lo, int rows, int N, int K, int ldx, const FusedEpi& e) {
     constexpr int PHASE = CHUNK * (LO ? 4 : 8);
-    const int slot = 24 + MODE * 4 + (LO ? 2 : 0);
+    const int slot = 40 + MODE * 4 + (LO ? 2 : 0);
     if (K == 2048) launch_stream_np<MODE, LO, 2048 / PHASE>(st, W, wpk, X, x_lo, rows, N, K, ldx, e, slot);
     else launch_stream_np<MODE, LO, 1024 / PHASE>(st, W, wpk, X, x_lo, rows, N, K, ldx, e, slot + 1);
 }
@@ -596,10 +624,10 @@ void launch_gemm_k_split(hipStream_t st, WMat Wm, const void* X, int ldx, long x
     const int gcap = std::max(1, std::min(group / planes, per_wave));
     const size_t lds = (size_t)KS_WAVES * 64 * 16 + (size_t)KS_WAVES * planes * gcap * 2048;
     if (x_lo) {
-        if (lds > 64 * 1024) raise_lds_limit((const void*)gemm_k_split_kernel<true>, 38);
+        if (lds > 64 * 1024) raise_lds_limit((const void*)gemm_k_split_kernel<true>, 48);
         hipLaunchKernelGGL((gemm_k_split_kernel<true>), grid, dim3(64 * KS_WAVES), lds, st, w, x, N, K, ldx, x_lo, wpk, gcap, e);
     } else {
-        if (lds > 64 * 1024) raise_lds_limit((const void*)gemm_k_split_kernel<false>, 39);
+        if (lds > 64 * 1024) raise_lds_limit((const void*)gemm_k_split_kernel<false>, 49);
         hipLaunchKernelGGL((gemm_k_split_kernel<false>), grid, dim3(64 * KS_WAVES), lds, st, w, x, N, K, ldx, 0L, wpk, gcap, e);
     }
 }

@@ -163,13 +163,22 @@ struct Runner {
             launch_qkv_post(st, dt, qa, kv);
             launch_attention(st, dt, g.q.as<float>(), toks, kv, kv_layer, M, c.nh, (float)std::pow((double)c.d, -0.5), g.attn.p, lo_attn);
         }
-        ks = ks_for(M, c.hidden, nq);
-        gemm(w.o, g.attn.p, M, c.hidden, nq, ks, nq, lo_attn);
-        launch_resid_norm(st, dt, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), w.o_bias, w.ls_attn, w.ln2, c.eps,
-                          g.x.as<float>(), g.xn.p, nullptr, M, c.hidden, lo_xn);
+        // o projection: in decode steps of a bf16 stack one launch adds the residual and leaves xn = T(x * ln2) with the per-tile
+        // sums of squares that gate|up turns into the row scale (instead of split-K slabs + a residual / norm pass)
+        const bool o_fused = fk && !w.ls_attn && o_fused_enabled() && g.ssB.p && g.ss_ld >= fused_rows(M) && c.hidden % 16 == 0 && nq % 64 == 0;
+        int nt_b = 0;
+        if (o_fused) {
+            nt_b = k_split_resid(w.o, g.attn.p, lo_attn, M, c.hidden, nq, w.o_bias, true, w.ln2, g.ssB.as<float>());
+        } else {
+            ks = ks_for(M, c.hidden, nq);
+            gemm(w.o, g.attn.p, M, c.hidden, nq, ks, nq, lo_attn);
+            launch_resid_norm(st, dt, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), w.o_bias, w.ls_attn, w.ln2, c.eps,
+                              g.x.as<float>(), g.xn.p, nullptr, M, c.hidden, lo_xn);
+        }
         if (fk) {
             FusedEpi e{};
             e.mode = FUSED_SWIGLU; e.act = g.act.p; e.act_lo = lo_act;
+            if (o_fused) { e.ss_in = g.ssB.as<float>(); e.ss_ld = g.ss_ld; e.ntiles_in = nt_b; e.H_in = c.hidden; e.eps = c.eps; }
             timed(M, 2 * c.inter, c.hidden, [&] { wide_gemm(w.gate_up_il, g.xn.p, c.hidden, lo_xn, M, 2 * c.inter, c.hidden, e); });
         } else {
             ks = ks_for(M, 2 * c.inter, c.hidden);
@@ -182,6 +191,13 @@ struct Runner {
                           g.x.as<float>(), xn_out, xn_f32_out, M, c.hidden, xn_out_lo);
     }
 
+    // QTTS_O_FUSED=1 switches the one-launch o projection on.  Measured on the 1.7B talker at 64 rows: 28 launches fewer per
+    // frame and the same single-stream frame time (4.99 ms either way: gate|up then sums 128 tiles of partials per row), but
+    // three sessions in flight lose 4 % (1698 against 1764 audio-s/s) to its 512 blocks of eight waves - so it stays off.
+    static bool o_fused_enabled() {
+        static const bool on = getenv("QTTS_O_FUSED") && atoi(getenv("QTTS_O_FUSED")) == 1;
+        return on;
+    }
     // q|k|v and gate|up of this stack can go through the full-K kernel for M tokens (QTTS_FULL_K=0: never)
     bool full_k_usable(const StackW& s, int M) const {
         static const bool off = getenv("QTTS_FULL_K") && atoi(getenv("QTTS_FULL_K")) == 0;

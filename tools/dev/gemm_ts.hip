@@ -1,16 +1,16 @@
-// Stand-alone driver of the decode GEMM kernels (no Python, no torch): launches one kernel variant back to back on rotating
-// weight copies and prints the average launch time and the weight bytes per second.  Meant for rocprofv3 (the program itself
-// goes after `--`, so counter collection needs no interpreter in between) and for comparing kernel variants.
+// In-kernel timeline of the finished-output decode GEMMs (development probe): tools/gemm_harness.cpp compiled together with
+// the kernel source and its wall-clock marks; prints where the first and the last block of the last launch spent their time.
 //   gemm_harness <stream|full_k|k_split|slab> M N K lo(0/1) [iters] [mode: 0 plain, 1 swiglu]
-// Build: hipcc -std=c++17 -O3 --offload-arch=gfx950 -I include -I qwen3-tts-rs_amd/csrc tools/gemm_harness.cpp \
-//        -L qwen3-tts-rs_amd -lqtts_hip -Wl,-rpath,'$ORIGIN/../qwen3-tts-rs_amd' -o tools/gemm_harness
+// Build: hipcc -std=c++17 -O3 --offload-arch=gfx950 -I include -I qwen3-tts-rs_amd/csrc -o tools/dev/gemm_ts tools/dev/gemm_ts.hip
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
-#include "kernels.hpp"
+#define QTTS_KERNEL_TS 1
+#define HARNESS_FUSED_ONLY 1
+#include "../../qwen3-tts-rs_amd/csrc/k_gemm_fused.hip"
 
 using namespace qtts;
 
@@ -73,6 +73,13 @@ int main(int argc, char** argv) {
         QTTS_HIP(hipEventElapsedTime(&ms, a, b));
         const double us = ms * 1e3 / iters;
         printf("%s M=%d N=%d K=%d lo=%d mode=%d: %.2f us/launch, %.1f GB/s of weights\n", kind.c_str(), M, N, K, (int)lo, mode, us, wbytes / us / 1e3);
+        unsigned long long ts[2][16];
+        QTTS_HIP(hipMemcpyFromSymbol(ts, HIP_SYMBOL(g_kernel_ts), sizeof(ts)));
+        for (int b = 0; b < 2; ++b) {
+            printf("  %s block:", b ? "last " : "first");
+            for (int i = 1; i <= 6; ++i) printf(" t%d %+.2f", i, (double)(long long)(ts[b][i] - ts[0][0]) / 100.0);
+            printf("   (own start %+.2f)\n", (double)(long long)(ts[b][0] - ts[0][0]) / 100.0);
+        }
     } catch (const Error& err) {
         fprintf(stderr, "error %d: %s\n", err.code, err.what());
         return 1;

@@ -5,6 +5,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #define CK(x)                                                                      \
@@ -22,16 +23,16 @@ __global__ void probe_kernel(float* p, int spin) {
     if (v == 12345.678f) p[0] = v;  // never true; keeps the loop
 }
 
-int main() {
-    const int chain = 640, reps = 20;
+int main(int argc, char** argv) {
+    const int chain = 640, reps = 20, max_streams = argc > 1 ? atoi(argv[1]) : 4;
     float* buf;
     CK(hipMalloc(&buf, 1 << 20));
     CK(hipMemset(buf, 0, 1 << 20));
-    const int grids[] = {1, 256, 1024};
+    const int grids[] = {256};
     const int spins[] = {0, 2000};
     for (int spin : spins)
         for (int grid : grids)
-            for (int ns = 1; ns <= 4; ++ns) {
+            for (int ns = 1; ns <= max_streams; ++ns) {
                 std::vector<hipStream_t> st(ns);
                 std::vector<hipGraphExec_t> ex(ns);
                 for (int s = 0; s < ns; ++s) {
