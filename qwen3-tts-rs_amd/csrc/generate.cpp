@@ -68,6 +68,7 @@ struct GenState {
     // activations (token-major rows)
     Workspace ws;                            // activation scratch shared by every layer
     DevBuf cp_in_t, cp_in_f, hid_scratch_f; // code-predictor inputs; rows [0,B) double as the talker's post-norm hidden
+    DevBuf cp_qkv_in;                        // first-layer q|k|v rows gathered from the model's tables (CpMemo)
     DevBuf text_rows, extra, trailing, tts_pad_dummy;
     DevBuf ibuf;                             // int scratch: ids / descriptors
     DevBuf toks_prompt, toks_dec, toks_cp;
@@ -472,9 +473,50 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
     const long row_stride = (long)max_new * G;
     int* d_step = g.step.as<int>();
 
+    // ---- tables of the code predictor's pass starts (CpMemo): built once per model, with this call's workspace and the decode
+    // kernels, 64 codes at a time.  QTTS_CP_MEMO=0 keeps the projection + q|k|v launches.
+    static const bool memo_off = getenv("QTTS_CP_MEMO") && atoi(getenv("QTTS_CP_MEMO")) == 0;
+    const int cp_nqkv = (c.cp.nh + 2 * c.cp.nkv) * c.cp.d;
+    const bool use_memo = fused_cp && !memo_off && m.proj && G > 2 && Vc % 64 == 0 && Hc % 4 == 0;
+    if (use_memo) {
+        CpMemo& mm = *m.cp_memo;
+        std::lock_guard<std::mutex> lock(mm.mu);
+        if (!mm.ready) {
+            const int tables = G - 2;
+            mm.x.alloc((size_t)tables * Vc * Hc * 4);
+            mm.qkv.alloc((size_t)tables * Vc * cp_nqkv * 4);
+            const LayerW& w0 = m.cp.layers[0];
+            R.split(false);
+            for (int t = 0; t < tables; ++t) {
+                for (int r0 = 0; r0 < Vc; r0 += 64) {
+                    const void* rows = (const char*)m.cp_emb[(size_t)t] + (size_t)r0 * H * es;
+                    const int nt = R.k_split_resid(m.proj, rows, 0, 64, Hc, H, m.proj_b, false, w0.ln1, g.ws.ssA.as<float>());
+                    FusedEpi e{};
+                    e.mode = FUSED_PLAIN; e.ss_in = g.ws.ssA.as<float>(); e.ss_ld = g.ws.ss_ld; e.ntiles_in = nt; e.H_in = Hc; e.eps = c.cp.eps;
+                    e.bias = w0.qkv_bias; e.out_f32 = g.ws.part.as<float>(); e.ld_out = cp_nqkv;
+                    R.wide_gemm(w0.qkv, g.ws.xn.p, Hc, 0, 64, cp_nqkv, Hc, e);
+                    const size_t row = (size_t)t * Vc + r0;
+                    QTTS_HIP(hipMemcpyAsync(mm.x.as<float>() + row * Hc, g.ws.x.p, (size_t)64 * Hc * 4, hipMemcpyDeviceToDevice, st));
+                    QTTS_HIP(hipMemcpyAsync(mm.qkv.as<float>() + row * cp_nqkv, g.ws.part.p, (size_t)64 * cp_nqkv * 4, hipMemcpyDeviceToDevice, st));
+                }
+            }
+            QTTS_HIP(hipStreamSynchronize(st));
+            R.split(true);
+            mm.tables = tables; mm.Vc = Vc; mm.Hc = Hc; mm.nqkv = cp_nqkv;
+            mm.ready = true;
+        }
+        g.cp_qkv_in.ensure((size_t)(B + 64) * cp_nqkv * 4);
+    }
+
+    // memo_table >= 0: the sampler also gathers the tabulated start of the next code-predictor pass for the code it drew
     auto sample = [&](const float* logits, int vocab, int gcol, bool talker, const void* next_table = nullptr, void* next_dst = nullptr,
-                      int next_dst_dtype = F32) {
+                      int next_dst_dtype = F32, int memo_table = -1) {
         SampleArgs a{};
+        if (memo_table >= 0) {
+            const CpMemo& mm = *m.cp_memo;
+            a.memo_x = mm.x.as<float>() + (size_t)memo_table * Vc * Hc; a.memo_x_dst = g.ws.x.as<float>(); a.memo_Hx = Hc;
+            a.memo_q = mm.qkv.as<float>() + (size_t)memo_table * Vc * cp_nqkv; a.memo_q_dst = g.cp_qkv_in.as<float>(); a.memo_Nq = cp_nqkv;
+        }
         a.next_table = next_table; a.next_dst = next_dst; a.next_H = H; a.next_table_bf16 = dt == BF16; a.next_dst_bf16 = next_dst_dtype == BF16;
         a.logits = logits; a.V = vocab; a.B = B;
         const double T = talker ? sp->temperature : sp->subtalker_temperature;
@@ -531,14 +573,18 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
             int nt = enter(g.cp_in_t.p, lo_cp, g.cp_in_f.as<float>(), 2 * B);
             nt = R.stack_fused(m.cp, 2 * B, ct, g.cp.kv, nt, false);
             head(0, (size_t)B, nt);
-            sample(g.ws.part.as<float>(), Vc, 1, false, G > 2 ? m.cp_emb[0] : nullptr, inj, in_dt);
+            if (use_memo) sample(g.ws.part.as<float>(), Vc, 1, false, nullptr, nullptr, F32, 0);
+            else sample(g.ws.part.as<float>(), Vc, 1, false, G > 2 ? m.cp_emb[0] : nullptr, inj, in_dt);
             for (int j = 1; j < G - 1; ++j) {  // code_predictor.rs:480-527
-                nt = enter(g.ws.act.p, 0, g.ws.q.as<float>(), B);   // embedding rows: exact in the model dtype, no remainder plane
+                // pass input: the embedding row of code j (exact in the model dtype, no remainder plane) -> x, xn, ssA; or, tabulated,
+                // x and the first layer's q|k|v rows as the sampler gathered them
+                if (!use_memo) nt = enter(g.ws.act.p, 0, g.ws.q.as<float>(), B);
                 R.uni_len = j + 2;  // every row: position j + 1, keys 0 .. j + 1 (what ct holds for this pass)
-                nt = R.stack_fused(m.cp, B, ct + 2 * B + (size_t)j * B, g.cp.kv, nt, true);
+                nt = R.stack_fused(m.cp, B, ct + 2 * B + (size_t)j * B, g.cp.kv, nt, true, use_memo ? g.cp_qkv_in.as<float>() : nullptr);
                 R.uni_len = 0;
                 head(j, 0, nt);
-                sample(g.ws.part.as<float>(), Vc, j + 1, false, j + 1 < G - 1 ? m.cp_emb[(size_t)j] : nullptr, inj, in_dt);
+                if (use_memo) sample(g.ws.part.as<float>(), Vc, j + 1, false, nullptr, nullptr, F32, j + 1 < G - 1 ? j : -1);
+                else sample(g.ws.part.as<float>(), Vc, j + 1, false, j + 1 < G - 1 ? m.cp_emb[(size_t)j] : nullptr, inj, in_dt);
             }
         } else {
         const long cxn = R.lo_xn;

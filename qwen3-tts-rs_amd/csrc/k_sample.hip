@@ -429,6 +429,14 @@ __global__ __launch_bounds__(256) void sample_kernel(SampleArgs a) {
             for (int i = tid * 4; i < H; i += 256 * 4) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(src + i);
         }
     }
+    if (a.memo_x) {
+        const float4* sx = reinterpret_cast<const float4*>(a.memo_x + (long)token * a.memo_Hx);
+        float4* dx = reinterpret_cast<float4*>(a.memo_x_dst + (long)b * a.memo_Hx);
+        for (int i = tid; i < a.memo_Hx / 4; i += 256) dx[i] = sx[i];
+        const float4* sq = reinterpret_cast<const float4*>(a.memo_q + (long)token * a.memo_Nq);
+        float4* dq = reinterpret_cast<float4*>(a.memo_q_dst + (long)b * a.memo_Nq);
+        for (int i = tid; i < a.memo_Nq / 4; i += 256) dq[i] = sq[i];
+    }
     if (tid == 0 && live) {
         a.codes_base[(long)b * a.row_stride + (long)step * a.G + a.g] = (unsigned)token;
         if (a.g == 0) {
@@ -444,6 +452,8 @@ void launch_sample(hipStream_t st, const SampleArgs& a) {
     QTTS_CHECK(a.B >= 1 && a.G >= 1 && a.g >= 0 && a.g < a.G && a.row_stride % a.G == 0 && a.max_steps >= 1 &&
                    (long)a.max_steps * a.G <= a.row_stride, ERR_SHAPE, "sample: bad shape");
     QTTS_CHECK(!a.do_sample || a.uniforms != nullptr, ERR_BAD_ARG, "sample: uniforms required when sampling");
+    QTTS_CHECK(a.memo_x == nullptr || (a.memo_x_dst && a.memo_q && a.memo_q_dst && a.memo_Hx % 4 == 0 && a.memo_Nq % 4 == 0), ERR_BAD_ARG,
+               "sample: bad tabulated-row description");
     QTTS_CHECK(a.next_table == nullptr || (a.next_dst != nullptr && a.next_H % 8 == 0 && (a.next_table_bf16 || !a.next_dst_bf16)), ERR_BAD_ARG,
                "sample: bad next-row description");
     hipLaunchKernelGGL(sample_kernel, dim3(a.B), dim3(256), 0, st, a);

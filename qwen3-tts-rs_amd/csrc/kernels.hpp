@@ -198,6 +198,13 @@ struct SampleArgs {
     const void* next_table;
     void* next_dst;
     int next_H, next_table_bf16, next_dst_bf16;
+    // optional: gather two f32 rows by the drawn token (tabulated start of the next code-predictor pass): memo_x[token] ->
+    // memo_x_dst row b (memo_Hx floats), memo_q[token] -> memo_q_dst row b (memo_Nq floats); both widths multiples of 4
+    const float* memo_x;
+    float* memo_x_dst;
+    const float* memo_q;
+    float* memo_q_dst;
+    int memo_Hx, memo_Nq;
 };
 void launch_sample(hipStream_t st, const SampleArgs& a);
 

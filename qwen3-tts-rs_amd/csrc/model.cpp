@@ -331,6 +331,7 @@ void Model::init_view(const Model& base) {
     QTTS_HIP(hipSetDevice(ctx->device));
     is_view = true;
     locks = base.locks;
+    cp_memo = base.cp_memo;
     dtype = base.dtype;
     cfg = base.cfg;
     codec = base.codec;

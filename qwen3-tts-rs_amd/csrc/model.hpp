@@ -128,10 +128,22 @@ struct SharedLocks {
     std::mutex codec, speaker, encoder;
 };
 
+// Code-predictor passes 1 .. groups - 2 start from the embedding row of the code just drawn.  What the first layer makes of such a
+// row before attention - the projected residual row x and its q|k|v row - depends on (codebook, code) only, so both are tabulated
+// once per model with the decode kernels themselves (same values bit for bit) and a pass gathers two rows instead of running a
+// projection and a q|k|v GEMM.  Shared by the sessions of a model.
+struct CpMemo {
+    std::mutex mu;
+    bool ready = false;
+    int tables = 0, Vc = 0, Hc = 0, nqkv = 0;
+    DevBuf x, qkv;  // [tables][Vc][Hc] and [tables][Vc][nqkv] f32
+};
+
 struct Model {
     Ctx* ctx = nullptr;
     bool is_view = false;  // a session: weights borrowed from another model, which must outlive it
     std::shared_ptr<SharedLocks> locks = std::make_shared<SharedLocks>();
+    std::shared_ptr<CpMemo> cp_memo = std::make_shared<CpMemo>();
     int dtype = BF16;
     ModelCfg cfg;
     CodecCfg codec;

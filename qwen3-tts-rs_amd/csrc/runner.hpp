@@ -252,19 +252,21 @@ struct Runner {
         return nqkv % 64 == 0 && (2 * c.inter) % 64 == 0 && c.hidden % 16 == 0 && (c.nh * c.d) % 64 == 0 && c.inter % 64 == 0;
     }
     // One decoder layer, five launches.  In: x, xn = T(x * ln1), ssA (nt_in tiles).  Out: x, xn = T(x * next_norm), ssA.
-    int layer_fused(const StackW& s, int l, int M, const Tok* toks, const KVView& kv, int kv_layer, const float* next_norm, int nt_in, bool decode) {
+    // qkv_rows: the layer's q|k|v rows [M][nqkv] f32 are already there (tabulated); the q|k|v GEMM is skipped and xn / ssA are not read
+    int layer_fused(const StackW& s, int l, int M, const Tok* toks, const KVView& kv, int kv_layer, const float* next_norm, int nt_in, bool decode,
+                    const float* qkv_rows = nullptr) {
         const StackCfg& c = s.cfg;
         const LayerW& w = s.layers[(size_t)l];
         const int nq = c.nh * c.d, nqkv = (c.nh + 2 * c.nkv) * c.d;
         QTTS_CHECK(lo_xn == 0, ERR_STATE, "fused decode layers take single-plane layer inputs");
-        {
+        if (!qkv_rows) {
             FusedEpi e{};
             e.mode = FUSED_PLAIN; e.ss_in = g.ssA.as<float>(); e.ss_ld = g.ss_ld; e.ntiles_in = nt_in; e.H_in = c.hidden; e.eps = c.eps;
             e.bias = w.qkv_bias; e.out_f32 = g.part.as<float>(); e.ld_out = nqkv;
             timed(M, nqkv, c.hidden, [&] { wide_gemm(w.qkv, g.xn.p, c.hidden, 0, M, nqkv, c.hidden, e); });
         }
         QkvPostArgs qa{};
-        qa.part = g.part.as<float>(); qa.KS = 1; qa.ks_stride = 0; qa.bias = nullptr;
+        qa.part = qkv_rows ? qkv_rows : g.part.as<float>(); qa.KS = 1; qa.ks_stride = 0; qa.bias = nullptr;
         qa.q_norm = w.q_norm; qa.k_norm = w.k_norm; qa.eps = c.eps; qa.cos = s.cos.as<float>(); qa.sin = s.sin.as<float>();
         qa.rope_mode = 0; qa.toks = toks; qa.M = M; qa.nh = c.nh; qa.nkv = c.nkv; qa.d = c.d; qa.layer = kv_layer;
         qa.q_out = g.q.as<float>(); qa.uni_len = decode ? uni_len : 0;
@@ -285,11 +287,12 @@ struct Runner {
         return k_split_resid(w.down, g.act.p, lo_act, M, c.hidden, c.inter, nullptr, true, next_norm, g.ssA.as<float>());
     }
     // whole stack; afterwards xn = T(x * final_norm) and ssA holds the returned number of tiles
-    int stack_fused(const StackW& s, int M, const Tok* toks, const KVView& kv, int nt_in, bool decode) {
+    // qkv_rows0: q|k|v rows of the first layer when they are already there (see layer_fused)
+    int stack_fused(const StackW& s, int M, const Tok* toks, const KVView& kv, int nt_in, bool decode, const float* qkv_rows0 = nullptr) {
         int nt = nt_in;
         for (int l = 0; l < s.cfg.layers; ++l) {
             const bool last = l + 1 == s.cfg.layers;
-            nt = layer_fused(s, l, M, toks, kv, l, last ? s.final_norm : s.layers[(size_t)l + 1].ln1, nt, decode);
+            nt = layer_fused(s, l, M, toks, kv, l, last ? s.final_norm : s.layers[(size_t)l + 1].ln1, nt, decode, l == 0 ? qkv_rows0 : nullptr);
         }
         return nt;
     }

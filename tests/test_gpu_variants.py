@@ -43,3 +43,33 @@ def test_variant_matches_golden(env):
     e = dict(os.environ, **env)
     r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + SCRIPT], env=e, capture_output=True, text=True, timeout=280)
     assert r.returncode == 0 and "variant ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+MEMO_SCRIPT = r"""
+import sys, os, hashlib
+import numpy as np
+sys.path.insert(0, ROOT)
+from qwen3_tts_rs_amd import GenerationRequest, SamplingConfig, synthetic_model
+m, cfg, ccfg, tmpl = synthetic_model("M0", dtype="bf16", codec=False)
+rng = np.random.default_rng(5)
+reqs = [GenerationRequest(text_ids=rng.integers(10, tmpl["text_hi"], size=6 + 3 * i).astype(np.int32), language="english",
+                          speaker="speaker1", seed=100 + i) for i in range(5)]
+out = m.generate(reqs, SamplingConfig(), 24)
+h = hashlib.sha256()
+for c in out.codes:
+    h.update(np.ascontiguousarray(c).tobytes())
+m.close()
+print("codes", h.hexdigest())
+"""
+
+
+def test_tabulated_pass_starts_change_nothing():
+    """The code predictor's tabulated pass starts (projection + first-layer q|k|v per (codebook, code)) hold exactly what the
+    launches they replace compute: sampled bf16 codes are the same with the tables switched off."""
+    digests = []
+    for env in ({}, {"QTTS_CP_MEMO": "0"}):
+        e = dict(os.environ, **env)
+        r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + MEMO_SCRIPT], env=e, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0 and "codes " in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+        digests.append(r.stdout.split("codes ")[1].split()[0])
+    assert digests[0] == digests[1]
