@@ -230,8 +230,9 @@ __global__ __launch_bounds__(256 * KH) void gemm_full_k_kernel(const bf16_t* __r
 
 // ------------------------------------------------------------------------------------------------ stream
 // Wide GEMMs at 64 token rows (q|k|v, gate|up of a 2048-wide stack): the X tile of the whole K range does not fit LDS, so a block
-// (four waves x 16 weight rows, 64 token rows) walks K in phases of PC chunks with two LDS buffers: while phase p is multiplied
-// out of buffer p & 1, the DMA of phase p + 1 fills the other buffer and the weight fragments of phase p + 1 travel to registers.
+// (four waves x 16 weight rows, 64 token rows) walks K in phases of PC chunks through a ring of four 32 KB LDS buffers: while
+// phase p is multiplied, the DMAs of phases p + 1 .. p + 3 are under way and the weight fragments of later phases travel to
+// registers.  (With two 64 KB buffers and the DMA one phase ahead every phase waited for its tile: 20.2 us against 17.9.)
 // The compiler serialises an LDS read behind every outstanding LDS DMA (it cannot tell the two buffers apart), so the fragment
 // reads are issued by hand (ds_read_b128 in inline assembly, waited for with counted s_waitcnt lgkmcnt) and the barriers are
 // bare s_barrier instructions behind counted s_waitcnt vmcnt.
@@ -297,27 +298,82 @@ struct StreamPhase {
     }
 };
 
+// The same phase walked by a wave that owns TWO 16-row weight tiles and half of the phase's chunks (PCH of the 2 PCH): every X
+// fragment read from LDS feeds four MFMAs instead of two, so a block's fragment traffic is half that of four waves which each
+// read the whole tile.  a[jt * PCH + c]: weight fragments of column tile jt, chunk c of this wave's half.
+template <int PCH, int PL>
+struct StreamPhase2 {
+    static constexpr int MT = 4, NB = PCH * PL * 2, PC = 2 * PCH;
+    template <int B>
+    static __device__ __forceinline__ void issue(u32x4_t (&f)[4], unsigned fa0, unsigned fa1) {
+        constexpr int c = B / (2 * PL), pl = (B >> 1) % PL, ih = B & 1;
+        constexpr int off = ((pl * PC + c) * MT + 2 * ih) * 2048;
+        lds_read16<off>(f[0], fa0);
+        lds_read16<off>(f[1], fa1);
+        lds_read16<off + 2048>(f[2], fa0);
+        lds_read16<off + 2048>(f[3], fa1);
+    }
+    template <int IH>
+    static __device__ __forceinline__ void multiply(const BFrag& a0, const BFrag& a1, const u32x4_t (&f)[4], f32x4_t (&acc)[2][MT]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            acc[0][2 * IH + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.v[0], __builtin_bit_cast(bf16x8_t, f[2 * i]), acc[0][2 * IH + i], 0, 0, 0);
+            acc[1][2 * IH + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v[0], __builtin_bit_cast(bf16x8_t, f[2 * i]), acc[1][2 * IH + i], 0, 0, 0);
+            acc[0][2 * IH + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.v[1], __builtin_bit_cast(bf16x8_t, f[2 * i + 1]), acc[0][2 * IH + i], 0, 0, 0);
+            acc[1][2 * IH + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1.v[1], __builtin_bit_cast(bf16x8_t, f[2 * i + 1]), acc[1][2 * IH + i], 0, 0, 0);
+        }
+    }
+    template <int B>
+    static __device__ __forceinline__ void pair(const BFrag (&a)[PC], u32x4_t (&fA)[4], u32x4_t (&fB)[4], f32x4_t (&acc)[2][MT], unsigned fa0, unsigned fa1) {
+        if constexpr (B < NB) {
+            constexpr int c = B / (2 * PL);
+            issue<B + 1>(fB, fa0, fa1);
+            lds_wait<4>(fA);
+            multiply<0>(a[c], a[PCH + c], fA, acc);
+            if constexpr (B + 2 < NB) {
+                issue<B + 2>(fA, fa0, fa1);
+                lds_wait<4>(fB);
+            } else {
+                lds_wait<0>(fB);
+            }
+            multiply<1>(a[c], a[PCH + c], fB, acc);
+            pair<B + 2>(a, fA, fB, acc, fa0, fa1);
+        }
+    }
+    static __device__ __forceinline__ void run(const BFrag (&a)[PC], f32x4_t (&acc)[2][MT], unsigned fa0, unsigned fa1) {
+        u32x4_t fA[4], fB[4];
+        issue<0>(fA, fa0, fa1);
+        pair<0>(a, fA, fB, acc, fa0, fa1);
+    }
+};
+
 constexpr int vmcnt_imm(int n) { return (n & 0xF) | ((n >> 4) << 14) | 0x0F70; }  // s_waitcnt vmcnt(n), other counters untouched
 
 // NP: number of phases, K = NP * PC * 64.  A template constant, so that the phase loop is straight-line code: at a loop
 // header the compiler's wait-count bookkeeping drains the whole weight ring.
-template <int MODE, bool LO, int NP>
+// SP2: the four compute waves form a 2 x 2 grid - two 32-column halves x two halves of every phase's chunks - instead of four
+// 16-column strips over the whole phase (half the LDS fragment reads; the two K halves exchange half of their tiles at the end).
+// X goes through a ring of four 32 KB buffers, requested three phases ahead, with ONE barrier per phase: when every wave has
+// arrived at the barrier of phase p, the DMA of phase p has landed (the loaders waited for it) and the multiply of phase p - 1
+// is over, so its buffer is free for phase p + 3.
+template <int MODE, bool LO, int NP, bool SP2>
 __global__ __launch_bounds__(512) void gemm_stream_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, int N, int K, int ldx,
                                                           long x_lo, int wpk, FusedEpi e) {
-    constexpr int MT = 4, PL = LO ? 2 : 1, PC = LO ? 4 : 8;
-    constexpr int UB = PL * PC * MT;          // units per buffer (64 KB)
+    constexpr int MT = 4, PL = LO ? 2 : 1, PC = LO ? 2 : 4, NBUF = 4;
+    constexpr int UB = PL * PC * MT;          // units per buffer (32 KB)
+    constexpr int BUF_BYTES = UB * 2048;
     constexpr int DMA_PER_WAVE = UB * 2 / 4;  // DMA instructions a loader wave issues per phase
-    constexpr int D = LO ? 5 : 2;             // phases of weight fragments in registers (160 / 128 registers): fetched D - 1 phases ahead
-    extern __shared__ uint4 smem[];           // two buffers of UB units, then 4 x 64 partial sums of squares
+    constexpr int D = LO ? 10 : 4;            // phases of weight fragments in registers (160 / 128 registers): fetched D - 1 phases ahead
+    extern __shared__ uint4 smem[];           // NBUF buffers of UB units, then 4 x 64 partial sums of squares
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = blockIdx.y * 64;
     constexpr int nP = NP;
-    float* ssq = reinterpret_cast<float*>(smem + 2 * UB * 128);
+    float* ssq = reinterpret_cast<float*>(smem + NBUF * UB * 128);
 
     // Two roles, because a wave's loads complete in order: a wave that waits for its DMA of phase p also waits for every
     // weight load it issued before, which would cap the weight prefetch at one phase (less than the HBM latency).
     if (wave >= 4) {
-        // ---- loader waves: X tiles of phase p + 1 into the idle buffer while phase p is multiplied
+        // ---- loader waves: the X tiles of phases p + 1 .. p + 3 travel while phase p is multiplied
         const int lw = wave - 4;
         auto dma_phase = [&](int p, int buf) __attribute__((always_inline)) {
 #pragma unroll
@@ -331,56 +387,103 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const bf16_t* __restri
         };
         row_sumsq(e, row0, 64, ssq);
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the sums are in LDS before this wave's first barrier
-        dma_phase(0, 0);
+#pragma unroll
+        for (int d = 0; d < NBUF - 1; ++d) dma_phase(min(d, nP - 1), d);
+#pragma unroll
         for (int p = 0; p < nP; ++p) {
-            const int buf = p & 1;
-            dma_phase(min(p + 1, nP - 1), buf ^ 1);  // branch-free: the last phase fetches itself once more into the idle buffer
-            __builtin_amdgcn_s_waitcnt(vmcnt_imm(DMA_PER_WAVE));  // this wave's DMA of phase p has landed
-            __builtin_amdgcn_s_barrier();                          // A: buffer `buf` is complete
-            __builtin_amdgcn_s_barrier();                          // B: every compute wave is done with `buf`
+            __builtin_amdgcn_s_waitcnt(vmcnt_imm((NBUF - 2) * DMA_PER_WAVE));  // this wave's DMA of phase p has landed (two later phases may be under way)
+            __builtin_amdgcn_s_barrier();
+            dma_phase(min(p + NBUF - 1, nP - 1), (p + NBUF - 1) % NBUF);      // branch-free: past the end the last phase is fetched again into an idle buffer
         }
         __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
         __builtin_amdgcn_s_barrier();  // matches the compute waves' barrier in front of the epilogue
         return;
     }
-    // ---- compute waves: 16 weight rows each, fragments straight to registers D - 1 phases ahead
     const int r = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 64 + wave * 16;
     const unsigned lds0 = (unsigned)reinterpret_cast<size_t>((__attribute__((address_space(3))) char*)smem);
-    const unsigned fa0 = lds0 + unit_slot(r, g, 0) * 16, fa1 = lds0 + unit_slot(r, g, 1) * 16;
-    const WTileB wt(W, n0, K, lane, wpk);
     const bool shared_w = gridDim.y > 1;
-    auto load_w = [&](int p, BFrag (&a)[PC]) __attribute__((always_inline)) {
+    if constexpr (SP2) {
+        // ---- compute waves as a 2 x 2 grid: column half ch (weight tiles 2 ch, 2 ch + 1), chunk half kh of every phase
+        constexpr int PCH = PC / 2;
+        const int ch = wave & 1, kh = wave >> 1;
+        const unsigned koff = (unsigned)kh * PCH * MT * 2048;  // this wave's chunks inside a plane of a buffer
+        const unsigned fa0 = lds0 + unit_slot(r, g, 0) * 16 + koff, fa1 = lds0 + unit_slot(r, g, 1) * 16 + koff;
+        const int n0 = blockIdx.x * 64 + ch * 32;
+        const WTileB wt0(W, n0, K, lane, wpk), wt1(W, n0 + 16, K, lane, wpk);
+        auto load_w = [&](int p, BFrag (&a)[PC]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int c = 0; c < PC; ++c) {
-            const bf16_t* src = wt.p + (size_t)(p * PC + c) * wt.cs;
-            if (QTTS_STREAM_DBG & 2) src = wt.p;  // one chunk over and over: served by the caches
-            if (shared_w) a[c].load(src, wt.hs);
-            else a[c].load_stream(src, wt.hs);
+            for (int c = 0; c < PCH; ++c) {
+                const size_t off = (size_t)(p * PC + kh * PCH + c) * wt0.cs;
+                if (shared_w) { a[c].load(wt0.p + off, wt0.hs); a[PCH + c].load(wt1.p + off, wt1.hs); }
+                else { a[c].load_stream(wt0.p + off, wt0.hs); a[PCH + c].load_stream(wt1.p + off, wt1.hs); }
+            }
+        };
+        f32x4_t acc[2][MT];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        BFrag ring[D][PC];  // every index below is a constant once the phase loop is unrolled
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d) load_w(min(d, nP - 1), ring[d]);
+#pragma unroll
+        for (int p = 0; p < nP; ++p) {
+            load_w(min(p + D - 1, nP - 1), ring[(p + D - 1) % D]);
+            __builtin_amdgcn_s_barrier();
+            StreamPhase2<PCH, PL>::run(ring[p % D], acc, fa0 + (p % NBUF) * BUF_BYTES, fa1 + (p % NBUF) * BUF_BYTES);
         }
-    };
-    f32x4_t acc[MT];
+        __builtin_amdgcn_s_barrier();  // the loader waves' sums of squares are visible, every buffer is idle (the loaders end here)
+        // The two K halves of a column half swap tiles: kh keeps row tiles 2 kh, 2 kh + 1 and hands the other two over, then adds
+        // what it receives (a + b and b + a are the same number, so both waves add "lower half + upper half").
+        f32x4_t* xch = reinterpret_cast<f32x4_t*>(smem);  // [wave][j][2][64]
+        f32x4_t keep[2][2];  // (selected with constant indices: a run-time index would put the accumulators in scratch memory)
 #pragma unroll
-    for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    // phase p out of `cur`; the ring slot that phase p - 1 has just released is refilled with phase p + D - 1
-    BFrag first[PC];
-    if (QTTS_STREAM_DBG & 8) load_w(0, first);
-    (void)first;
-    auto step = [&](int p, int buf, const BFrag (&cur)[PC], BFrag (&fill)[PC]) __attribute__((always_inline)) {
-        load_w(min(p + D - 1, nP - 1), fill);
-        __builtin_amdgcn_s_barrier();  // A
-        if (QTTS_STREAM_DBG & 8) StreamPhase<PC, PL>::run(first, acc, fa0 + buf * (UB * 2048), fa1 + buf * (UB * 2048));
-        else if (!(QTTS_STREAM_DBG & 4)) StreamPhase<PC, PL>::run(cur, acc, fa0 + buf * (UB * 2048), fa1 + buf * (UB * 2048));
-        else acc[0] += __builtin_bit_cast(f32x4_t, cur[0].v[0]) + __builtin_bit_cast(f32x4_t, cur[PC - 1].v[1]);
-        __builtin_amdgcn_s_barrier();  // B
-    };
-    BFrag ring[D][PC];  // every index below is a constant once the phase loop is unrolled
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int d = 0; d < D - 1; ++d) load_w(min(d, nP - 1), ring[d]);
+            for (int i = 0; i < 2; ++i) {
+                xch[((wave * 2 + j) * 2 + i) * 64 + lane] = kh ? acc[j][i] : acc[j][2 + i];
+                keep[j][i] = kh ? acc[j][2 + i] : acc[j][i];
+            }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        const int other = wave ^ 2;
+        f32x4_t fin[2][2];
 #pragma unroll
-    for (int p = 0; p < nP; ++p) step(p, p & 1, ring[p % D], ring[(p + D - 1) % D]);
-    __builtin_amdgcn_s_barrier();  // the loader waves' partial sums of squares are visible
-    finished_tile_epilogue<MT, MODE>(acc, e, ssq, row0, n0, N, r, g);
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fin[j][i] = keep[j][i] + xch[((other * 2 + j) * 2 + i) * 64 + lane];
+        finished_tile_epilogue<2, MODE>(fin[0], e, ssq + 32 * kh, row0 + 32 * kh, n0, N, r, g);
+        finished_tile_epilogue<2, MODE>(fin[1], e, ssq + 32 * kh, row0 + 32 * kh, n0 + 16, N, r, g);
+    } else {
+        // ---- compute waves: 16 weight rows each, fragments straight to registers D - 1 phases ahead
+        const int n0 = blockIdx.x * 64 + wave * 16;
+        const unsigned fa0 = lds0 + unit_slot(r, g, 0) * 16, fa1 = lds0 + unit_slot(r, g, 1) * 16;
+        const WTileB wt(W, n0, K, lane, wpk);
+        auto load_w = [&](int p, BFrag (&a)[PC]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < PC; ++c) {
+                const bf16_t* src = wt.p + (size_t)(p * PC + c) * wt.cs;
+                if (QTTS_STREAM_DBG & 2) src = wt.p;  // one chunk over and over: served by the caches
+                if (shared_w) a[c].load(src, wt.hs);
+                else a[c].load_stream(src, wt.hs);
+            }
+        };
+        f32x4_t acc[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        BFrag ring[D][PC];
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d) load_w(min(d, nP - 1), ring[d]);
+#pragma unroll
+        for (int p = 0; p < nP; ++p) {
+            load_w(min(p + D - 1, nP - 1), ring[(p + D - 1) % D]);
+            __builtin_amdgcn_s_barrier();
+            if (!(QTTS_STREAM_DBG & 4)) StreamPhase<PC, PL>::run(ring[p % D], acc, fa0 + (p % NBUF) * BUF_BYTES, fa1 + (p % NBUF) * BUF_BYTES);
+            else acc[0] += __builtin_bit_cast(f32x4_t, ring[p % D][0].v[0]) + __builtin_bit_cast(f32x4_t, ring[p % D][PC - 1].v[1]);
+        }
+        __builtin_amdgcn_s_barrier();  // the loader waves' partial sums of squares are visible
+        finished_tile_epilogue<MT, MODE>(acc, e, ssq, row0, n0, N, r, g);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ k_split
@@ -565,8 +668,8 @@ void launch_gemm_full_k(hipStream_t st, WMat Wm, const void* X, int ldx, long x_
 bool gemm_stream_fits(int M, int N, int K, bool lo) {
     return fused_rows(M) % 64 == 0 && N % 64 == 0 && (K == 1024 || K == 2048);  // the instantiated phase counts
 }
-// Measured at 64 rows (us per launch, weights streamed from HBM): N = 12288, K = 2048, two planes: 20.2 against 34.6 for the
-// whole-K tile kernel and 23.8 + 5.3 for split-K slabs + the SwiGLU pass; N = 4096: 15.5 against 10.7 (64 blocks are too few);
+// Measured at 64 rows (us per launch, weights streamed from HBM): N = 12288, K = 2048, two planes: 17.9 against 34.6 for the
+// whole-K tile kernel and 23.8 + 5.3 for split-K slabs + the SwiGLU pass; N = 4096: 12.8 against 10.4 (64 blocks are too few);
 // K = 1024: the whole-K kernel wins at every N.  QTTS_GEMM_STREAM: 0 never, 1 (default) by this rule, 2 whenever it fits.
 bool gemm_stream_preferred(int M, int N, int K, bool lo) {
     static const int mode = getenv("QTTS_GEMM_STREAM") ? atoi(getenv("QTTS_GEMM_STREAM")) : 1;
@@ -576,13 +679,22 @@ bool gemm_stream_preferred(int M, int N, int K, bool lo) {
 
 template <int MODE, bool LO, int NP>
 static void launch_stream_np(hipStream_t st, const bf16_t* W, int wpk, const bf16_t* X, long x_lo, int rows, int N, int K, int ldx, const FusedEpi& e, int slot) {
+    // QTTS_STREAM_GRID=1: compute waves as a 2 x 2 grid.  Same time as four strips alone on the GPU (17.8 against 17.9 us at
+    // N = 12288, 4.80 ms per frame either way) and no better with three sessions in flight (1799 against 1825 audio-s/s): the kernel
+    // is bound on its load side, not by the fragment reads the grid halves - the strips stay the default.
+    static const bool strips = !(getenv("QTTS_STREAM_GRID") && atoi(getenv("QTTS_STREAM_GRID")) == 1);
     const size_t lds = (size_t)2 * 64 * 1024 + 4 * 64 * 4;
-    raise_lds_limit((const void*)gemm_stream_kernel<MODE, LO, NP>, slot);
-    hipLaunchKernelGGL((gemm_stream_kernel<MODE, LO, NP>), dim3(N / 64, rows / 64), dim3(512), lds, st, W, X, N, K, ldx, x_lo, wpk, e);
+    if (strips) {
+        raise_lds_limit((const void*)gemm_stream_kernel<MODE, LO, NP, false>, slot);
+        hipLaunchKernelGGL((gemm_stream_kernel<MODE, LO, NP, false>), dim3(N / 64, rows / 64), dim3(512), lds, st, W, X, N, K, ldx, x_lo, wpk, e);
+    } else {
+        raise_lds_limit((const void*)gemm_stream_kernel<MODE, LO, NP, true>, slot + 8);
+        hipLaunchKernelGGL((gemm_stream_kernel<MODE, LO, NP, true>), dim3(N / 64, rows / 64), dim3(512), lds, st, W, X, N, K, ldx, x_lo, wpk, e);
+    }
 }
 template <int MODE, bool LO>
 static void launch_stream_inst(hipStream_t st, const bf16_t* W, int wpk, const bf16_t* X, long x_lo, int rows, int N, int K, int ldx, const FusedEpi& e) {
-    constexpr int PHASE = CHUNK * (LO ? 4 : 8);
+    constexpr int PHASE = CHUNK * (LO ? 2 : 4);
     const int slot = 40 + MODE * 4 + (LO ? 2 : 0);
     if (K == 2048) launch_stream_np<MODE, LO, 2048 / PHASE>(st, W, wpk, X, x_lo, rows, N, K, ldx, e, slot);
     else launch_stream_np<MODE, LO, 1024 / PHASE>(st, W, wpk, X, x_lo, rows, N, K, ldx, e, slot + 1);
@@ -624,10 +736,10 @@ void launch_gemm_k_split(hipStream_t st, WMat Wm, const void* X, int ldx, long x
     const int gcap = std::max(1, std::min(group / planes, per_wave));
     const size_t lds = (size_t)KS_WAVES * 64 * 16 + (size_t)KS_WAVES * planes * gcap * 2048;
     if (x_lo) {
-        if (lds > 64 * 1024) raise_lds_limit((const void*)gemm_k_split_kernel<true>, 48);
+        if (lds > 64 * 1024) raise_lds_limit((const void*)gemm_k_split_kernel<true>, 60);
         hipLaunchKernelGGL((gemm_k_split_kernel<true>), grid, dim3(64 * KS_WAVES), lds, st, w, x, N, K, ldx, x_lo, wpk, gcap, e);
     } else {
-        if (lds > 64 * 1024) raise_lds_limit((const void*)gemm_k_split_kernel<false>, 49);
+        if (lds > 64 * 1024) raise_lds_limit((const void*)gemm_k_split_kernel<false>, 61);
         hipLaunchKernelGGL((gemm_k_split_kernel<false>), grid, dim3(64 * KS_WAVES), lds, st, w, x, N, K, ldx, 0L, wpk, gcap, e);
     }
 }
