@@ -655,7 +655,8 @@ void launch_gemm_full_k(hipStream_t st, WMat Wm, const void* X, int ldx, long x_
     // row tiles per block: the most that fits LDS and still gives about 192 blocks (a 64-row launch of 64 column blocks
     // becomes 256 blocks of 16 rows)
     int mt = rows >= 64 ? 4 : rows / 16;
-    while (mt > 1 && (full_k_lds(K, mt, planes, kh) > FULL_K_LDS_MAX || (long)(N / 64) * (rows / (16 * mt)) < 192)) mt >>= 1;
+    static const long min_blocks = getenv("QTTS_FULL_K_MIN_BLOCKS") ? atol(getenv("QTTS_FULL_K_MIN_BLOCKS")) : 192;
+    while (mt > 1 && (full_k_lds(K, mt, planes, kh) > FULL_K_LDS_MAX || (long)(N / 64) * (rows / (16 * mt)) < min_blocks)) mt >>= 1;
 #define QTTS_FULL_K(MTV)                                                                                        \
     if (e.mode == FUSED_PLAIN) launch_full_k_mode<MTV, FUSED_PLAIN>(st, w, wpk, x, x_lo, rows, N, K, ldx, e);   \
     else launch_full_k_mode<MTV, FUSED_SWIGLU>(st, w, wpk, x, x_lo, rows, N, K, ldx, e)

@@ -4,6 +4,7 @@
 //   gemm_harness <stream|full_k|k_split|slab> M N K lo(0/1) [iters] [mode: 0 plain, 1 swiglu]
 // Build: hipcc -std=c++17 -O3 --offload-arch=gfx950 -I include -I qwen3-tts-rs_amd/csrc tools/gemm_harness.cpp \
 //        -L qwen3-tts-rs_amd -lqtts_hip -Wl,-rpath,'$ORIGIN/../qwen3-tts-rs_amd' -o tools/gemm_harness
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -62,6 +63,33 @@ int main(int argc, char** argv) {
         };
         for (int i = 0; i < 10; ++i) launch(i);
         QTTS_HIP(hipDeviceSynchronize());
+        // HARNESS_STREAMS=n: the same chain of launches replayed from one graph per stream on n streams at once (all write the
+        // same outputs: only the timing means anything)
+        if (const char* hs = getenv("HARNESS_STREAMS")) {
+            const int ns = atoi(hs);
+            std::vector<hipStream_t> sts(ns);
+            std::vector<hipGraphExec_t> ex(ns);
+            for (int q = 0; q < ns; ++q) {
+                QTTS_HIP(hipStreamCreateWithFlags(&sts[q], hipStreamNonBlocking));
+                hipGraph_t gr;
+                st = sts[q];
+                QTTS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                for (int i = 0; i < iters; ++i) launch(i + q * 7);
+                QTTS_HIP(hipStreamEndCapture(st, &gr));
+                QTTS_HIP(hipGraphInstantiate(&ex[q], gr, nullptr, nullptr, 0));
+                QTTS_HIP(hipGraphDestroy(gr));
+            }
+            for (int q = 0; q < ns; ++q) QTTS_HIP(hipGraphLaunch(ex[q], sts[q]));
+            QTTS_HIP(hipDeviceSynchronize());
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int rep = 0; rep < 5; ++rep)
+                for (int q = 0; q < ns; ++q) QTTS_HIP(hipGraphLaunch(ex[q], sts[q]));
+            QTTS_HIP(hipDeviceSynchronize());
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / (5.0 * iters);
+            printf("%s M=%d N=%d K=%d lo=%d mode=%d on %d streams: %.2f us per launch per stream, %.2f us per launch overall\n", kind.c_str(), M, N, K,
+                   (int)lo, mode, ns, us, us / ns);
+            return 0;
+        }
         hipEvent_t a, b;
         QTTS_HIP(hipEventCreate(&a));
         QTTS_HIP(hipEventCreate(&b));
