@@ -121,6 +121,44 @@ void launch_resid_norm(hipStream_t st, int dtype, const float* resid, const floa
                            resid_out, (float*)xn, xn_f32, H, 0L);
 }
 
+// Split-K combine + residual for a consumer that applies the RMSNorm scale itself (the finished-output GEMMs, k_gemm_fused.hip):
+// x = resid + sum of slabs + bias;  xb = T(x * norm_w) (+ remainder plane);  ss_out[slice][row] = sum of x^2 over the slice's
+// 256 columns.  One wave per (row, slice): no block-wide reduction, eight times the blocks of resid_norm_kernel.
+__global__ __launch_bounds__(64) void resid_partial_kernel(const float* __restrict__ resid, const float* __restrict__ part, int KS,
+                                                           long ks_stride, const float* __restrict__ bias,
+                                                           const float* __restrict__ norm_w, float* resid_out, bf16_t* xb, long xb_lo,
+                                                           float* ss_out, long ss_ld, int H) {
+    const long row = blockIdx.x;
+    const int slice = blockIdx.y;
+    const int i = slice * 256 + threadIdx.x * 4;
+    const float4 w = *reinterpret_cast<const float4*>(norm_w + i);
+    const float4 x = resid_combine(resid, part, KS, ks_stride, bias, nullptr, row * H + i, i);
+    *reinterpret_cast<float4*>(resid_out + row * H + i) = x;
+    const float y[4] = {x.x * w.x, x.y * w.y, x.z * w.z, x.w * w.w};
+    u16 hb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) hb[q] = f32_to_bf16_bits(y[q]);
+    bf16_t* o = xb + row * H + i;
+    *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)hb[0] | ((unsigned)hb[1] << 16), (unsigned)hb[2] | ((unsigned)hb[3] << 16));
+    if (xb_lo) {
+        u16 lb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lb[q] = f32_to_bf16_bits(y[q] - bf16_bits_to_f32(hb[q]));
+        *reinterpret_cast<uint2*>(o + xb_lo) = make_uint2((unsigned)lb[0] | ((unsigned)lb[1] << 16), (unsigned)lb[2] | ((unsigned)lb[3] << 16));
+    }
+    const float ss = wave_sum(x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w);
+    if (threadIdx.x == 0) ss_out[(long)slice * ss_ld + row] = ss;
+}
+
+int launch_resid_partial(hipStream_t st, const float* resid, const float* part, int KS, long ks_stride, const float* bias,
+                         const float* norm_w, float* resid_out, void* xb, long xb_lo, float* ss_out, long ss_ld, int M, int H) {
+    QTTS_CHECK(H % 256 == 0 && M >= 1 && ss_ld >= M, ERR_SHAPE, "resid_partial: H must be a multiple of 256");
+    QTTS_CHECK(resid_out && xb && norm_w && ss_out && xb_lo % 4 == 0, ERR_BAD_ARG, "resid_partial: null output");
+    hipLaunchKernelGGL(resid_partial_kernel, dim3(M, H / 256), dim3(64), 0, st, resid, part, KS, ks_stride, bias, norm_w, resid_out,
+                       (bf16_t*)xb, xb_lo, ss_out, ss_ld, H);
+    return H / 256;
+}
+
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void swiglu_kernel(const float* __restrict__ part, int KS, long ks_stride, T* act, int I,

@@ -104,6 +104,10 @@ void launch_chain_b(hipStream_t st, const float* in, float* out, int n, int bloc
 void launch_resid_norm(hipStream_t st, int dtype, const float* resid, const float* part, int KS, long ks_stride,
                        const float* bias, const float* scale, const float* norm_w, float eps, float* resid_out, void* xn,
                        float* xn_f32, int M, int H, long xn_lo = 0);
+// split-K combine + residual; xb = bf16(x * norm_w) (+ remainder plane xb_lo elements behind) and per-row sums of x^2 over slices of
+// 256 columns -> ss_out[slice][ss_ld] for a consumer GEMM that applies 1/rms (FusedEpi::ss_in).  Returns the number of slices.
+int launch_resid_partial(hipStream_t st, const float* resid, const float* part, int KS, long ks_stride, const float* bias,
+                         const float* norm_w, float* resid_out, void* xb, long xb_lo, float* ss_out, long ss_ld, int M, int H);
 // act = silu(sum part[..][0:I]) * sum part[..][I:2I] -> dtype   (candle_nn::ops::swiglu)
 void launch_swiglu(hipStream_t st, int dtype, const float* part, int KS, long ks_stride, void* act, int M, int I, long act_lo = 0);
 // out = act(sum_ks part + bias): act 0 none, 1 silu, 2 erf-GELU; out_dtype F32/BF16 independent of the weight dtype

@@ -78,6 +78,9 @@ struct Runner {
     // decode launches whose tokens all sit at one position (row m = token m, keys 0 .. uni_len - 1) say so here: the attention
     // kernel then takes the description from its arguments instead of loading it (0 = read the token table)
     int uni_len = 0;
+    // g.xn holds T(x * norm weight) whose 1/rms is still to be applied: this many slices of partial sums of squares are in ssA
+    // (0: xn is normalised).  Set and consumed by consecutive layer() calls of one stack.
+    int xn_tiles = 0;
     Model& m;
     Workspace& g;
     GemmTimer* timer;
@@ -144,10 +147,17 @@ struct Runner {
         const int nq = c.nh * c.d, nqkv = (c.nh + 2 * c.nkv) * c.d;
         // decode steps of bf16 stacks: q|k|v and gate|up own finished outputs (no split-K slabs; SwiGLU inside the GEMM)
         const bool fk = decode && full_k_usable(s, M);
+        // decode steps of a bf16 stack: the two residual / norm passes leave xn = T(x * w) and per-slice sums of squares, and the
+        // GEMM that reads xn applies 1/rms (one wave per 256 columns instead of a block-wide reduction per row)
+        const bool pn = fk && partial_norm_enabled() && !w.ls_attn && !w.ls_mlp && c.hidden % 256 == 0 && g.ssA.p && g.ssB.p &&
+                        g.ss_ld >= fused_rows(M);
+        QTTS_CHECK(xn_tiles == 0 || fk, ERR_STATE, "layer: the input's norm scale is pending but this path cannot apply it");
         int ks = fk ? 1 : ks_for(M, nqkv, c.hidden);
         if (fk) {
             FusedEpi e{};
             e.mode = FUSED_PLAIN; e.bias = w.qkv_bias; e.out_f32 = g.part.as<float>(); e.ld_out = nqkv;
+            if (xn_tiles) { e.ss_in = g.ssA.as<float>(); e.ss_ld = g.ss_ld; e.ntiles_in = xn_tiles; e.H_in = c.hidden; e.eps = c.eps; }
+            xn_tiles = 0;
             timed(M, nqkv, c.hidden, [&] { wide_gemm(w.qkv, g.xn.p, c.hidden, lo_xn, M, nqkv, c.hidden, e); });
         } else {
             gemm(w.qkv, g.xn.p, M, nqkv, c.hidden, ks, c.hidden, lo_xn);
@@ -172,13 +182,17 @@ struct Runner {
         } else {
             ks = ks_for(M, c.hidden, nq);
             gemm(w.o, g.attn.p, M, c.hidden, nq, ks, nq, lo_attn);
-            launch_resid_norm(st, dt, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), w.o_bias, w.ls_attn, w.ln2, c.eps,
-                              g.x.as<float>(), g.xn.p, nullptr, M, c.hidden, lo_xn);
+            if (pn)
+                nt_b = launch_resid_partial(st, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), w.o_bias, w.ln2, g.x.as<float>(),
+                                            g.xn.p, lo_xn, g.ssB.as<float>(), g.ss_ld, M, c.hidden);
+            else
+                launch_resid_norm(st, dt, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), w.o_bias, w.ls_attn, w.ln2, c.eps,
+                                  g.x.as<float>(), g.xn.p, nullptr, M, c.hidden, lo_xn);
         }
         if (fk) {
             FusedEpi e{};
             e.mode = FUSED_SWIGLU; e.act = g.act.p; e.act_lo = lo_act;
-            if (o_fused) { e.ss_in = g.ssB.as<float>(); e.ss_ld = g.ss_ld; e.ntiles_in = nt_b; e.H_in = c.hidden; e.eps = c.eps; }
+            if (nt_b) { e.ss_in = g.ssB.as<float>(); e.ss_ld = g.ss_ld; e.ntiles_in = nt_b; e.H_in = c.hidden; e.eps = c.eps; }
             timed(M, 2 * c.inter, c.hidden, [&] { wide_gemm(w.gate_up_il, g.xn.p, c.hidden, lo_xn, M, 2 * c.inter, c.hidden, e); });
         } else {
             ks = ks_for(M, 2 * c.inter, c.hidden);
@@ -187,8 +201,18 @@ struct Runner {
         }
         ks = ks_for(M, c.hidden, c.inter);
         gemm(w.down, g.act.p, M, c.hidden, c.inter, ks, c.inter, lo_act);
-        launch_resid_norm(st, dt, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), nullptr, w.ls_mlp, next_norm, c.eps,
-                          g.x.as<float>(), xn_out, xn_f32_out, M, c.hidden, xn_out_lo);
+        if (pn && xn_out == g.xn.p && !xn_f32_out && xn_out_lo == lo_xn) {  // the next layer of the stack reads xn: it applies the scale
+            xn_tiles = launch_resid_partial(st, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), nullptr, next_norm, g.x.as<float>(),
+                                            g.xn.p, lo_xn, g.ssA.as<float>(), g.ss_ld, M, c.hidden);
+        } else {
+            launch_resid_norm(st, dt, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), nullptr, w.ls_mlp, next_norm, c.eps,
+                              g.x.as<float>(), xn_out, xn_f32_out, M, c.hidden, xn_out_lo);
+        }
+    }
+    // QTTS_PARTIAL_NORM=0: residual + RMSNorm passes of the decode layers as one block per row again
+    static bool partial_norm_enabled() {
+        static const bool off = getenv("QTTS_PARTIAL_NORM") && atoi(getenv("QTTS_PARTIAL_NORM")) == 0;
+        return !off;
     }
 
     // QTTS_O_FUSED=1 switches the one-launch o projection on.  Measured on the 1.7B talker at 64 rows: 28 launches fewer per
@@ -301,6 +325,7 @@ struct Runner {
     // final_xn_lo: remainder-plane offset of final_xn (0 = none)
     void stack(const StackW& s, int M, const Tok* toks, const KVView& kv, void* final_xn, float* final_xn_f32, bool kv_per_layer = true,
                bool decode = false, long final_xn_lo = 0) {
+        xn_tiles = 0;  // the caller's xn is normalised
         for (int l = 0; l < s.cfg.layers; ++l) {
             const bool last = l + 1 == s.cfg.layers;
             layer(s, l, M, toks, kv, kv_per_layer ? l : 0, last ? s.final_norm : s.layers[(size_t)l + 1].ln1, last ? final_xn : g.xn.p,
