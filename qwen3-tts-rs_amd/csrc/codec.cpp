@@ -48,7 +48,7 @@ struct CodecState {
     int maxpad = 0;  // leading zero rows of the strips inside the vocoder blocks
     // run-time buffers (grown on demand, kept between calls)
     Workspace ws;
-    DevBuf kv, toks, meta, codes, A, Bf, R, Rf, acc, wav;
+    DevBuf kv, toks, tiles, meta, codes, A, Bf, R, Rf, acc, wav;
 };
 
 // Streaming decode session: the transformer's keys/values live in a ring per row, and the last `ctx_cap` frames of codes and
@@ -427,7 +427,12 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         if (!sc) s.kv.ensure(((size_t)U + 1) * pp * page_elems * es);  // row U: dump pages for the padding rows
         s.toks.ensure(toks.size() * sizeof(Tok));
         QTTS_HIP(hipMemcpyAsync(s.toks.p, toks.data(), toks.size() * sizeof(Tok), hipMemcpyHostToDevice, st));
-        QTTS_HIP(hipStreamSynchronize(st));  // toks is a local
+        // the strips' rows are runs of consecutive positions: banded attention in tiles of up to 64 queries on the matrix cores
+        std::vector<AttnTile> tiles;
+        build_attn_tiles(toks.data(), M, tiles);
+        s.tiles.ensure(tiles.size() * sizeof(AttnTile));
+        QTTS_HIP(hipMemcpyAsync(s.tiles.p, tiles.data(), tiles.size() * sizeof(AttnTile), hipMemcpyHostToDevice, st));
+        QTTS_HIP(hipStreamSynchronize(st));  // toks and tiles are locals
         // one-shot decodes reuse one layer's worth of pages for every layer; a session keeps all layers
         KVView kv{s.kv.p, 0, PAGE, c.kv_heads, c.head_dim, pp, nullptr};
         if (sc) {
@@ -448,6 +453,8 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
             s.xf.max_pos = n;
         }
         Runner run(m, s.ws, nullptr);
+        run.tiles = s.tiles.as<AttnTile>();
+        run.n_tiles = (int)tiles.size();
         // input_proj (+bias) starts the residual stream
         int ks = run.ks_for(M, Hd, s.latP);
         run.gemm(s.in_proj.wm(), s.Bf.p, M, Hd, s.latP, ks, s.latP, lo);

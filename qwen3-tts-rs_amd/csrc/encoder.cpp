@@ -64,7 +64,7 @@ struct EncoderState {
     } group[2];
     // run-time buffers
     Workspace ws;
-    DevBuf audio, nsamp, meta, X, A, Hh, D, acc, res, res_t, kv, toks, codes;
+    DevBuf audio, nsamp, meta, X, A, Hh, D, acc, res, res_t, kv, toks, tiles, codes;
 };
 
 void finalize_encoder(Model& m) {
@@ -306,6 +306,10 @@ void run_encode_audio(Model& m, const float* audio, const int* n_samples, int B,
             }
         s.toks.ensure(toks.size() * sizeof(Tok));
         QTTS_HIP(hipMemcpyAsync(s.toks.p, toks.data(), toks.size() * sizeof(Tok), hipMemcpyHostToDevice, st));
+        std::vector<AttnTile> tiles;
+        build_attn_tiles(toks.data(), M, tiles);
+        s.tiles.ensure(tiles.size() * sizeof(AttnTile));
+        QTTS_HIP(hipMemcpyAsync(s.tiles.p, tiles.data(), tiles.size() * sizeof(AttnTile), hipMemcpyHostToDevice, st));
         QTTS_HIP(hipStreamSynchronize(st));
         const size_t page_elems = (size_t)2 * ENC_HEADS * ENC_PAGE * ENC_HD;
         s.kv.ensure(((size_t)U + 1) * pp * page_elems * es);
@@ -322,6 +326,11 @@ void run_encode_audio(Model& m, const float* audio, const int* n_samples, int B,
             s.max_pos = n;
         }
         Runner run(m, s.ws, nullptr);
+        run.tiles = s.tiles.as<AttnTile>();
+        run.n_tiles = (int)tiles.size();
+        run.split(false);
+        StackCfg acfg{};
+        acfg.d = ENC_HD; acfg.nh = ENC_HEADS; acfg.nkv = ENC_HEADS;
         float* x = s.ws.x.as<float>();
         float* part = s.ws.part.as<float>();
         launch_resid_layernorm(st, dt, x, nullptr, 0, 0, nullptr, s.layer[0].ln1w, s.layer[0].ln1b, 1e-5f, x, s.ws.xn.p, M, ENC_DIM);
@@ -333,7 +342,7 @@ void run_encode_audio(Model& m, const float* audio, const int* n_samples, int B,
             qa.part = part; qa.KS = ks; qa.ks_stride = run.kstride(M, 3 * ENC_DIM); qa.eps = 1e-5f; qa.cos = s.cos.as<float>(); qa.sin = s.sin.as<float>();
             qa.toks = s.toks.as<Tok>(); qa.M = M; qa.nh = ENC_HEADS; qa.nkv = ENC_HEADS; qa.d = ENC_HD; qa.layer = 0; qa.q_out = s.ws.q.as<float>();
             launch_qkv_post(st, dt, qa, kv);
-            launch_attention(st, dt, s.ws.q.as<float>(), s.toks.as<Tok>(), kv, 0, M, ENC_HEADS, 1.0f / std::sqrt((float)ENC_HD), s.ws.attn.p);
+            run.attention(acfg, s.toks.as<Tok>(), kv, 0, M, 1.0f / std::sqrt((float)ENC_HD));
             ks = run.ks_for(M, ENC_DIM, ENC_DIM);
             run.gemm(y.o, s.ws.attn.p, M, ENC_DIM, ENC_DIM, ks, ENC_DIM);
             launch_resid_layernorm(st, dt, x, part, ks, run.kstride(M, ENC_DIM), y.ls_a, y.ln2w, y.ln2b, 1e-5f, x, s.ws.xn.p, M, ENC_DIM);

@@ -71,7 +71,7 @@ struct GenState {
     DevBuf cp_qkv_in;                        // first-layer q|k|v rows gathered from the model's tables (CpMemo)
     DevBuf text_rows, extra, trailing, tts_pad_dummy;
     DevBuf ibuf;                             // int scratch: ids / descriptors
-    DevBuf toks_prompt, toks_dec, toks_cp;
+    DevBuf toks_prompt, tiles_prompt, toks_dec, toks_cp;
     DevBuf row_len, step, eos_step, active, hist, uniforms, codes, trailing_len, tts_pad;
     DevBuf trace_logits, trace_hidden, trace_cp;
     StackRun talker, cp;
@@ -390,6 +390,17 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
             for (size_t k = 0; k < pl.trail_idx[(size_t)i].size(); ++k) trail_flat[(size_t)i * Tt_max + k] = pl.trail_idx[(size_t)i][k];
         QTTS_HIP(hipMemcpyAsync(d_trail, trail_flat.data(), trail_flat.size() * 4, hipMemcpyHostToDevice, st));
         QTTS_HIP(hipMemcpyAsync(g.toks_prompt.p, pl.p_toks.data(), (size_t)Ttot * sizeof(Tok), hipMemcpyHostToDevice, st));
+        // every prefill chunk's tokens cut into runs of one row (tiles of the matrix-core attention kernel; m0 counts from the chunk)
+        std::vector<AttnTile> ptiles, ctiles;
+        std::vector<size_t> ptile_off;
+        for (int o = 0; o < Ttot; o += chunk_rows) {
+            build_attn_tiles(pl.p_toks.data() + o, std::min(chunk_rows, Ttot - o), ctiles);
+            ptile_off.push_back(ptiles.size());
+            ptiles.insert(ptiles.end(), ctiles.begin(), ctiles.end());
+        }
+        ptile_off.push_back(ptiles.size());
+        g.tiles_prompt.ensure(std::max<size_t>(ptiles.size(), 1) * sizeof(AttnTile));
+        QTTS_HIP(hipMemcpyAsync(g.tiles_prompt.p, ptiles.data(), ptiles.size() * sizeof(AttnTile), hipMemcpyHostToDevice, st));
         if (!pl.extra_rows.empty()) QTTS_HIP(hipMemcpyAsync(g.extra.p, pl.extra_rows.data(), pl.extra_rows.size() * 4, hipMemcpyHostToDevice, st));
         if (!pl.icl_rows.empty()) {  // sum_ref_code_embeddings (generation.rs:242-273) into the extra rows
             g.icl.ensure((pl.icl_codes.size() + pl.icl_rows.size()) * 4);
@@ -438,7 +449,11 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
             launch_resid_norm(st, dt, g.ws.x.as<float>(), nullptr, 0, 0, nullptr, nullptr, m.talker.layers[0].ln1, c.talker.eps, g.ws.x.as<float>(),
                               g.ws.xn.p, nullptr, M, H, g.ws.lo_xn);
             // final norm output reuses act (T) and q (f32) as scratch rows
+            R.tiles = g.tiles_prompt.as<AttnTile>() + ptile_off[(size_t)(o / chunk_rows)];
+            R.n_tiles = (int)(ptile_off[(size_t)(o / chunk_rows) + 1] - ptile_off[(size_t)(o / chunk_rows)]);
             R.stack(m.talker, M, g.toks_prompt.as<Tok>() + o, g.talker.kv, g.ws.act.p, g.ws.q.as<float>(), true, false, g.ws.lo_act);
+            R.tiles = nullptr;  // the code predictor's two-token prefill keeps the per-token kernel
+            R.n_tiles = 0;
             last_src.clear();
             last_dst.clear();
             for (int i = 0; i < nb; ++i)

@@ -6,22 +6,11 @@
 //   (nn/attention/mod.rs:359-472; the additive 0/-inf masks become the key range in Tok).
 // Both are HBM-bound: K/V are read once, straight to registers with 16-byte loads (8 head dims per
 // lane, D/8 lanes per key), online softmax in f32, one block per (token, kv head).
-#include "device_utils.hpp"
-#include "kernels.hpp"
+#include "attn_common.hpp"
 
 #include <cstdlib>
 
 namespace qtts {
-
-template <typename T>
-__device__ __forceinline__ T* kv_ptr(const KVView& kv, int layer, int row, int pos, int which, int g) {
-    // without a table every row owns max_pages consecutive pages (saves a dependent load in front of every K/V access)
-    const int pidx = row * kv.max_pages + ((pos / kv.page_tokens) & kv.page_mask);
-    const int page = kv.page_table ? kv.page_table[pidx] : pidx;
-    const int slot = pos % kv.page_tokens;
-    return (T*)kv.base + (size_t)layer * kv.layer_stride +
-           ((((size_t)page * 2 + which) * kv.nkv + g) * kv.page_tokens + slot) * kv.d;
-}
 
 template <typename T>
 __global__ __launch_bounds__(64) void qkv_post_kernel(QkvPostArgs a, KVView kv) {

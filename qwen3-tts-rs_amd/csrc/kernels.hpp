@@ -3,6 +3,8 @@
 #pragma once
 #include "common.hpp"
 
+#include <vector>
+
 namespace qtts {
 
 // One token in flight: which KV-cache row it belongs to, its position (RoPE + cache slot) and the
@@ -177,6 +179,20 @@ void launch_attention(hipStream_t st, int dtype, const float* q, const Tok* toks
 // qkv_post + attention in one launch for decode steps: every token's newest key is its own position and no other token
 // of the launch attends to it
 void launch_attention_decode(hipStream_t st, int dtype, const QkvPostArgs& a, const KVView& kv, float scale, void* out, long out_lo = 0);
+
+// ---- k_attn_tile.hip: attention on the matrix cores for launches whose tokens come in runs (prefill chunks, the codec's
+// banded transformer).  A tile = up to ATTN_TILE_TOKENS tokens m0 .. m0 + count - 1 of the launch that belong to one cache row at
+// consecutive positions; [k0, k1) covers the key ranges of all of them (each token still sees only its own range).
+constexpr int ATTN_TILE_TOKENS = 64;
+struct AttnTile {
+    int m0, count, row, k0, k1;
+};
+// cuts the M tokens of a launch into tiles (any token order is legal: a token that continues no run starts a tile of its own)
+void build_attn_tiles(const Tok* toks, int M, std::vector<AttnTile>& tiles);
+bool attention_tiles_supported(int d, int nh, int nkv);
+// same contract as launch_attention; the keys and values a tile sees are fetched once per tile and shared through LDS
+void launch_attention_tiles(hipStream_t st, int dtype, const float* q, const Tok* toks, const AttnTile* tiles, int ntiles, const KVView& kv,
+                            int layer, int nh, float scale, void* out, long out_lo = 0);
 
 // ---- k_sample.hip
 struct SampleArgs {

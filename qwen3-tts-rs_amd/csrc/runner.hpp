@@ -81,6 +81,10 @@ struct Runner {
     // g.xn holds T(x * norm weight) whose 1/rms is still to be applied: this many slices of partial sums of squares are in ssA
     // (0: xn is normalised).  Set and consumed by consecutive layer() calls of one stack.
     int xn_tiles = 0;
+    // prefill-style launches (decode == false) whose tokens come in runs of one cache row: the launch's tokens cut into tiles
+    // (device array, build_attn_tiles) send their attention through the matrix-core tile kernel; null = one block per token
+    const AttnTile* tiles = nullptr;
+    int n_tiles = 0;
     Model& m;
     Workspace& g;
     GemmTimer* timer;
@@ -171,7 +175,7 @@ struct Runner {
             launch_attention_decode(st, dt, qa, kv, (float)std::pow((double)c.d, -0.5), g.attn.p, lo_attn);
         } else {
             launch_qkv_post(st, dt, qa, kv);
-            launch_attention(st, dt, g.q.as<float>(), toks, kv, kv_layer, M, c.nh, (float)std::pow((double)c.d, -0.5), g.attn.p, lo_attn);
+            attention(c, toks, kv, kv_layer, M, (float)std::pow((double)c.d, -0.5));
         }
         // o projection: in decode steps of a bf16 stack one launch adds the residual and leaves xn = T(x * ln2) with the per-tile
         // sums of squares that gate|up turns into the row scale (instead of split-K slabs + a residual / norm pass)
@@ -208,6 +212,15 @@ struct Runner {
             launch_resid_norm(st, dt, g.x.as<float>(), g.part.as<float>(), ks, kstride(M, c.hidden), nullptr, w.ls_mlp, next_norm, c.eps,
                               g.x.as<float>(), xn_out, xn_f32_out, M, c.hidden, xn_out_lo);
         }
+    }
+    // attention of a launch whose keys and values are all in the cache: tiles on the matrix cores when the caller described
+    // the launch's runs (QTTS_ATTN_TILES=0: always one block per token and kv head)
+    void attention(const StackCfg& c, const Tok* toks, const KVView& kv, int kv_layer, int M, float scale) {
+        static const bool off = getenv("QTTS_ATTN_TILES") && atoi(getenv("QTTS_ATTN_TILES")) == 0;
+        if (tiles && n_tiles > 0 && !off && attention_tiles_supported(c.d, c.nh, c.nkv))
+            launch_attention_tiles(st, dt, g.q.as<float>(), toks, tiles, n_tiles, kv, kv_layer, c.nh, scale, g.attn.p, lo_attn);
+        else
+            launch_attention(st, dt, g.q.as<float>(), toks, kv, kv_layer, M, c.nh, scale, g.attn.p, lo_attn);
     }
     // QTTS_PARTIAL_NORM=0: residual + RMSNorm passes of the decode layers as one block per row again
     static bool partial_norm_enabled() {
@@ -299,7 +312,7 @@ struct Runner {
             launch_attention_decode(st, dt, qa, kv, scale, g.attn.p, lo_attn);
         } else {
             launch_qkv_post(st, dt, qa, kv);
-            launch_attention(st, dt, g.q.as<float>(), toks, kv, kv_layer, M, c.nh, scale, g.attn.p, lo_attn);
+            attention(c, toks, kv, kv_layer, M, scale);
         }
         const int nt_b = k_split_resid(w.o, g.attn.p, lo_attn, M, c.hidden, nq, w.o_bias, true, w.ln2, g.ssB.as<float>());
         {

@@ -49,7 +49,9 @@ def test_small_model_batch_one_decode_and_codec():
         req = GenerationRequest(text_ids=text, language="english", speaker_embed=xvec)
         a = m.generate([req], _greedy(), 40)
         b = m.generate([req], _greedy(), 40, use_graph=False)
-        assert np.array_equal(a.codes, b.codes) and a.num_steps == 40
+        # (a random-init model may reach EOS before the 40 frames: the length is whatever the greedy path decides)
+        assert np.array_equal(a.codes, b.codes) and a.num_steps == b.num_steps and 2 <= a.num_steps <= 40
+        assert a.effective_lengths == b.effective_lengths and a.effective_lengths[0] >= 2
         wav = m.decode_output(a)[0]
         assert len(wav) == 1920 * a.effective_lengths[0] - 555 and np.isfinite(wav).all() and np.abs(wav).max() <= 1.0
         # the same utterance inside a batch of other utterances: its logits stay within the bf16 tolerance for as long as
