@@ -140,6 +140,13 @@ typedef struct {
     /* Optional trace of the code predictor's logits (eager launches only, like logits / hidden):
      * [n][max_new][num_code_groups - 1][code predictor vocab]. */
     float* cp_logits;
+    /* 1: the rows of a qtts_generate(_ex) batch draw from ONE MT19937 stream, seeded with reqs[0].seed, in the order of the
+     * reference's global generator (nn/mt_rng.rs:22): per frame the talker draws of rows 0 .. n-1 (nn/generation.rs:1055-1060),
+     * then for each residual codebook the draws of rows 0 .. n-1 (nn/code_predictor.rs:468-472,517-522); a greedy stage draws
+     * nothing.  A caller that hands the reference's own batch to one call gets the reference's tokens.  0 (default): every
+     * request owns the stream of its seed, so a row's tokens do not depend on its batch.  Not available with continuous
+     * batching (the draw order of a slot schedule has no counterpart in the reference). */
+    int shared_rng_stream;
 } qtts_gen_debug;
 
 /* ConditionalGeneration::generate (nn/generation.rs:815-1194) for n independent utterances decoded as

@@ -121,7 +121,7 @@ class Oracle:
 
     # ------------------------------------------------------------------ requests
     def _req(self, text_ids, prefill, speaker_token=-1, speaker_embed=None, instruct_ids=None, non_streaming=True,
-             ref_text_ids=None, ref_codes=None, max_new_tokens=0, trace=False):
+             ref_text_ids=None, ref_codes=None, max_new_tokens=0, trace=False, rng_stride=1, rng_offset=0):
         text_ids = np.ascontiguousarray(text_ids, np.uint32)
         prefill = np.ascontiguousarray(prefill, np.int32)
         ins = np.ascontiguousarray(instruct_ids, np.uint32) if instruct_ids is not None else np.zeros(0, np.uint32)
@@ -130,7 +130,7 @@ class Oracle:
         se = np.ascontiguousarray(speaker_embed, np.float32) if speaker_embed is not None else np.zeros(1, np.float32)
         ints = np.array([len(text_ids), len(ins), len(prefill), speaker_token, 1 if speaker_embed is not None else 0,
                          1 if non_streaming else 0, len(rt), rc.shape[0] if ref_codes is not None else 0,
-                         max_new_tokens, 1, 1 if trace else 0], np.int32)
+                         max_new_tokens, 1, 1 if trace else 0, rng_stride, rng_offset], np.int32)
         return text_ids, ins, prefill, se, rt, rc, ints
 
     def generate(self, text_ids, prefill, sampling: dict, max_new_tokens: int, seed: int = 0, trace: bool = False, **kw):

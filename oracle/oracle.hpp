@@ -70,7 +70,21 @@ struct MT19937 {
     explicit MT19937(uint32_t seed) { reseed(seed); }
     void reseed(uint32_t seed);
     uint32_t next_u32();
-    float uniform() { return (float)(next_u32() & 0x00FFFFFFu) / 16777216.0f; }
+    // A strided view (stride n, offset b) yields row b's share of ONE stream that n rows draw from in turn: the reference
+    // keeps a single global generator (mt_rng.rs:22) and, per frame, draws for rows 0 .. n-1 at the talker (generation.rs:
+    // 1055-1060) and then again for rows 0 .. n-1 at every residual codebook (code_predictor.rs:468-472,517-522), so row b
+    // owns the elements b, b + n, b + 2n, ... of the stream.  stride 1 / offset 0 is the plain stream.
+    int stride = 1, offset = 0;
+    bool primed = false;
+    float uniform() {
+        if (!primed) {
+            for (int i = 0; i < offset; ++i) next_u32();
+            primed = true;
+        }
+        const uint32_t v = next_u32();
+        for (int i = 1; i < stride; ++i) next_u32();
+        return (float)(v & 0x00FFFFFFu) / 16777216.0f;
+    }
 };
 // sample_vectorized (mt_rng.rs:116-162) for count a multiple of 16.
 void randn_vectorized(MT19937& rng, float* out, int count);

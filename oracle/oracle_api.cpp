@@ -113,7 +113,8 @@ static SamplingConfig sampling_from(const double* s) {
 }
 
 // One utterance through ConditionalGeneration::generate.  ints[]: n_text, n_instruct, n_prefill, speaker_token,
-// has_spk_embed, non_streaming, n_ref_text, ref_T, max_new_tokens, use_seed, trace.
+// has_spk_embed, non_streaming, n_ref_text, ref_T, max_new_tokens, use_seed, trace, rng_stride, rng_offset (the utterance is
+// row rng_offset of rng_stride rows that share the stream of `seed`: MT19937::stride; 1, 0 = a stream of its own).
 int orc_generate(void* hv, const uint32_t* text_ids, const uint32_t* instruct_ids, const int* prefill,
                  const float* spk_embed, const uint32_t* ref_text_ids, const uint32_t* ref_codes, const int* ints,
                  const double* sampling, uint64_t seed, uint32_t* codes_out, int* num_steps, int* eff_len,
@@ -132,6 +133,8 @@ int orc_generate(void* hv, const uint32_t* text_ids, const uint32_t* instruct_id
     if (ints[7] > 0) r.ref_codes.assign(ref_codes, ref_codes + (size_t)ints[7] * h->model.cfg.groups);
     SamplingConfig s = sampling_from(sampling);
     MT19937 rng((uint32_t)seed);
+    rng.stride = ints[11] > 0 ? ints[11] : 1;
+    rng.offset = ints[12];
     GenOutput out;
     h->model.generate(r, s, ints[8], &rng, ints[10] != 0, out);
     std::memcpy(codes_out, out.codes.data(), out.codes.size() * sizeof(uint32_t));
@@ -287,6 +290,13 @@ void orc_mt_u32(uint32_t seed, int n, uint32_t* out) {
 }
 void orc_mt_uniform(uint32_t seed, int n, float* out) {
     MT19937 r(seed);
+    for (int i = 0; i < n; ++i) out[i] = r.uniform();
+}
+// row `offset` of `stride` rows that share the stream of `seed` (MT19937::stride)
+void orc_mt_uniform_strided(uint32_t seed, int n, int stride, int offset, float* out) {
+    MT19937 r(seed);
+    r.stride = stride;
+    r.offset = offset;
     for (int i = 0; i < n; ++i) out[i] = r.uniform();
 }
 void orc_randn_vectorized(uint32_t seed, int n, float* out) {

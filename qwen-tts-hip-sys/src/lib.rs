@@ -83,6 +83,7 @@ pub struct qtts_gen_debug {
     pub chunk_user: *mut c_void,
     pub min_new_tokens: c_int,
     pub cp_logits: *mut c_float,
+    pub shared_rng_stream: c_int,
 }
 
 extern "C" {

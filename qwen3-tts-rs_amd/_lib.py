@@ -44,7 +44,7 @@ CHUNK_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_int
 class GenDebug(C.Structure):
     _fields_ = [("logits", C.POINTER(C.c_float)), ("hidden", C.POINTER(C.c_float)), ("use_graph", C.c_int),
                 ("profile_gemm", C.c_int), ("first_frames", C.c_int), ("chunk_cb", CHUNK_CB), ("chunk_user", C.c_void_p),
-                ("min_new_tokens", C.c_int), ("cp_logits", C.POINTER(C.c_float))]
+                ("min_new_tokens", C.c_int), ("cp_logits", C.POINTER(C.c_float)), ("shared_rng_stream", C.c_int)]
 
 
 EXPORTS = ["qtts_init", "qtts_shutdown", "qtts_last_error", "qtts_stream", "qtts_model_create", "qtts_model_load_tensor",

@@ -243,6 +243,8 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
     g.timer.shape.clear();
     const bool trace_l = dbg && dbg->logits, trace_h = dbg && dbg->hidden, trace_c = dbg && dbg->cp_logits;
     const bool tracing = trace_l || trace_h || trace_c;
+    const bool shared_rng = dbg && dbg->shared_rng_stream != 0;
+    QTTS_CHECK(!streaming || !shared_rng, ERR_BAD_ARG, "generate: one draw stream for all rows needs the plain batch");
     QTTS_CHECK(!streaming || !(tracing || (dbg && dbg->chunk_cb)), ERR_BAD_ARG, "generate: traces and the first-chunk hook need the plain batch");
 
     // ------------------------------------------------------------------ sizes over every request (the buffers the frame graph
@@ -354,7 +356,22 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
         g.toks_prompt.ensure((size_t)Ttot * sizeof(Tok));
         // uniforms in the reference's draw order per utterance: frame by frame, cb0 first then codebooks 1..G-1
         // (generation.rs:1055-1060, code_predictor.rs:468-472,517-522); a greedy stage consumes no draw.
-        if (sp->do_sample || sp->subtalker_do_sample) {
+        if (shared_rng && (sp->do_sample || sp->subtalker_do_sample)) {
+            // one stream for the whole batch in the reference's order (mt_rng.rs:22): per frame the talker draws of rows
+            // 0 .. n-1, then codebook by codebook the draws of rows 0 .. n-1
+            const qtts_request& r0 = reqs[ids[0]];
+            uint64_t seed = r0.seed;
+            if (!r0.use_seed)
+                seed = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
+            HostMT rng((uint32_t)seed);
+            std::vector<float> u((size_t)nb * max_new * G, 0.f);
+            for (int s2 = 0; s2 < max_new; ++s2)
+                for (int j = 0; j < G; ++j) {
+                    if (!(j == 0 ? sp->do_sample : sp->subtalker_do_sample)) continue;
+                    for (int i = 0; i < nb; ++i) u[((size_t)rws[(size_t)i] * max_new + s2) * G + j] = rng.uniform();
+                }
+            copy_sync(g.uniforms.p, u.data(), u.size() * 4, hipMemcpyHostToDevice, st);
+        } else if (sp->do_sample || sp->subtalker_do_sample) {
             std::vector<float> u((size_t)max_new * G, 0.f);
             for (int i = 0; i < nb; ++i) {
                 const qtts_request& rq = reqs[ids[(size_t)i]];

@@ -270,14 +270,16 @@ class Model:
     # ------------------------------------------------------------------ generation
     def generate(self, requests: Sequence[GenerationRequest], sampling: SamplingConfig, max_new_tokens: int,
                  trace: bool = False, use_graph: bool = True, profile_gemm: bool = False, first_frames: int = 0,
-                 on_first_chunk=None, min_new_tokens: int = 0, slots: int = 0) -> Output:
+                 on_first_chunk=None, min_new_tokens: int = 0, slots: int = 0, shared_rng_stream: bool = False) -> Output:
         """ConditionalGeneration::generate (nn/generation.rs:815) over a batch of independent utterances.
         slots > 0: continuous batching (qtts_generate_continuous) - the utterances go through at most `slots` rows, a finished
         row's slot is given to the next queued utterance, and every utterance gets the frames a batch of one would produce:
         Output.codes is padded to the longest one, Output.steps_per_utterance holds each one's own count.
         on_first_chunk(codes (batch, first_frames, groups)) is called once the first `first_frames` frames of every row
         exist, while generation continues afterwards (first-audio hook; the reference has no counterpart).
-        min_new_tokens > 0 keeps EOS suppressed for that many frames (fixed-length throughput runs; 0 = the reference's 2)."""
+        min_new_tokens > 0 keeps EOS suppressed for that many frames (fixed-length throughput runs; 0 = the reference's 2).
+        shared_rng_stream: all rows draw from one MT19937 stream (seed of the first request) in the order of the reference's
+        global generator (nn/mt_rng.rs:22, nn/generation.rs:1055-1060) instead of one stream per request."""
         n = len(requests)
         G = self.num_code_groups
         V = self.config["talker_config"]["vocab_size"]
@@ -333,6 +335,7 @@ class Model:
         dbg.use_graph = int(use_graph)
         dbg.profile_gemm = int(profile_gemm)
         dbg.min_new_tokens = int(min_new_tokens)
+        dbg.shared_rng_stream = int(bool(shared_rng_stream))
         cb_err = []
         if on_first_chunk is not None and first_frames > 0:
             def _cb(_user, ptr, nrows, frames):

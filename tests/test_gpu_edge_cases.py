@@ -109,6 +109,33 @@ def test_sampling_variants(bind, name, delta):
         m.close()
 
 
+@pytest.mark.parametrize("delta", [dict(do_sample=True, subtalker_do_sample=True), dict(do_sample=False, subtalker_do_sample=True),
+                                   dict(do_sample=True, subtalker_do_sample=False)], ids=["both", "subtalker-only", "talker-only"])
+def test_shared_draw_stream_follows_the_reference_order(bind, delta):
+    """shared_rng_stream: the rows of a batch draw from ONE MT19937 stream in the order of the reference's global generator
+    (nn/mt_rng.rs:22: per frame rows 0..n-1 at the talker, generation.rs:1055-1060, then rows 0..n-1 at every residual codebook,
+    code_predictor.rs:468-472,517-522).  Row b of n therefore owns elements b, b + n, ... of the stream, which is how the
+    oracle reproduces each row on its own."""
+    from qwen3_tts_rs_amd import GenerationRequest, SamplingConfig, synth
+    m, o, cfg, tmpl = _pair(bind)
+    try:
+        sampling = dict(BASE, **delta)
+        sc = SamplingConfig(**{k: sampling[k] for k in SamplingConfig().__dict__ if k in sampling})
+        texts = [synth.synthetic_text_ids(tmpl, 10 + 3 * i, i) for i in range(3)]
+        reqs = [GenerationRequest(text_ids=t, language="english", speaker="speaker1", seed=42) for t in texts]
+        out = m.generate(reqs, sc, 24, shared_rng_stream=True)
+        for i, t in enumerate(texts):
+            r = o.generate(t, bind.resolve_codec_prefill(cfg, "english", "speaker1"), sampling, 24, seed=42,
+                           speaker_token=bind.resolve_speaker_token(cfg, "speaker1"), rng_stride=len(texts), rng_offset=i)
+            assert r["num_steps"] >= 2 and np.array_equal(r["codes"], out.codes[i][:r["num_steps"]]), f"utterance {i}"
+        own = m.generate(reqs, sc, 24)      # one stream per request: rows 1, 2 see other draws
+        assert not np.array_equal(own.codes[1], out.codes[1])
+        with pytest.raises(Exception):
+            m.generate(reqs, sc, 8, slots=2, shared_rng_stream=True)
+    finally:
+        m.close()
+
+
 def test_single_frame_and_minimal_text(bind):
     from qwen3_tts_rs_amd import synth
     m, o, cfg, tmpl = _pair(bind)

@@ -54,6 +54,18 @@ def test_mt19937_reference_stream(bind):
     assert ((u >= 0) & (u < 1)).all()
 
 
+def test_strided_view_of_a_shared_stream(bind):
+    """Row b of n rows that draw in turn from one generator (mt_rng.rs:22; draw order generation.rs:1055-1060) owns the
+    elements b, b + n, ... of its stream."""
+    u = np.zeros(60, np.float32)
+    bind.lib().orc_mt_uniform(42, 60, u.ctypes.data_as(C.c_void_p))
+    for n in (1, 3, 4):
+        for b in range(n):
+            v = np.zeros(60 // n, np.float32)
+            bind.lib().orc_mt_uniform_strided(42, 60 // n, n, b, v.ctypes.data_as(C.c_void_p))
+            assert np.array_equal(v, u[b::n][:60 // n])
+
+
 def test_temperature(bind, kats):
     k = kats["temperature"]
     for c in k["cases"]:
