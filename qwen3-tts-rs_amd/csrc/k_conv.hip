@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
 // what bounds it.  The input channels are walked in phases of `cph` channels so that the tile of 256 rows + halo stays in LDS
 // whatever the layer's width; the weight stream is prefetched across phase boundaries.
 template <typename T, int MT, int NT, int WN>
-__global__ __launch_bounds__(256) void conv_tile_kernel(const T* __restrict__ W, int wpk, const T* __restrict__ X, int K, int C, int taps, int dil,
+__global__ __launch_bounds__(256, (MT * NT <= 32 && sizeof(T) == 2) ? 2 : 1) void conv_tile_kernel(const T* __restrict__ W, int wpk, const T* __restrict__ X, int K, int C, int taps, int dil,
                                                         int cph, ConvEpi e) {
     using F = CFrag<T>;
     extern __shared__ uint4 tile[];
@@ -363,22 +363,24 @@ template <typename T>
 bool try_tile(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, int taps, int dil, const ConvEpi& e) {
     static const bool off = getenv("QTTS_CONV_TILE2") && atoi(getenv("QTTS_CONV_TILE2")) == 0;
     static const long min_rows = getenv("QTTS_CONV_TILE2_ROWS") ? atol(getenv("QTTS_CONV_TILE2_ROWS")) : 1;
-    static const long min_k = getenv("QTTS_CONV_TILE2_K") ? atol(getenv("QTTS_CONV_TILE2_K")) : 5000;
+    static const long min_k = getenv("QTTS_CONV_TILE2_K") ? atol(getenv("QTTS_CONV_TILE2_K")) : 2600;
     const long halo = (long)(taps - 1) * dil;
-    // one block per CU (348 registers per lane): nothing hides its tile load and its epilogue, so it only wins where the K walk
-    // is long
-    // (measured on the vocoder: wins for 7-tap convs over >= 768 channels, for the wide two-tap transposed convs, and where the
-    // halo of a dilated conv would push the other kernel's tile past 64 KB; loses on everything narrower)
+    // at most two blocks per CU (221 registers per lane, up to 80 KB of LDS): little hides its tile load and its epilogue, so it
+    // only wins where the K walk is long
+    // (measured on the vocoder: wins for 7-tap convs over >= 384 channels, for the wide two-tap transposed convs, and where the
+    // halo of a dilated conv would push the other kernel's tile past 64 KB; no gain on anything narrower or on 1x1 convs)
     const bool long_k = (long)taps * C >= min_k;
     const bool wide_ct = taps == 2 && (long)taps * C >= 1536 && e.N >= 1920;
     const bool big_halo = (size_t)(64 + halo) * C * sizeof(T) > (size_t)64 * 1024;
     if (off || e.M < min_rows || halo > 128 || 256 + halo + 8 > CONV_HALO_SLACK || (e.M + 255) / 256 > 0x7fffffffL ||
         !(long_k || wide_ct || big_halo))
         return false;
-    // channels per phase: as many as keep the tile of 256 rows + halo within 96 KB
+    // channels per phase: as many as keep the tile of 256 rows + halo within 80 KB (bf16: two blocks per CU, so that one
+    // block's tile load and epilogue run under the other's K walk) or 96 KB (f32: the accumulators leave room for one block)
+    const size_t tile_cap = (size_t)(sizeof(T) == 2 ? 80 : 96) * 1024;
     int cph = 0;
     for (int c = C; c >= 64; c -= 64)
-        if (C % c == 0 && (size_t)(256 + halo) * c * sizeof(T) <= (size_t)96 * 1024) { cph = c; break; }
+        if (C % c == 0 && (size_t)(256 + halo) * c * sizeof(T) <= tile_cap) { cph = c; break; }
     if (cph == 0) return false;
     if (e.N % 128 == 0) launch_tile<T, 8, 4, 2>(st, W, wpk, X, K, C, taps, dil, cph, e);
     else if (e.N % 192 == 0) launch_tile<T, 8, 6, 2>(st, W, wpk, X, K, C, taps, dil, cph, e);
@@ -392,8 +394,11 @@ bool try_tile(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, int
 // second, short K walk over that tile, and only then comes the epilogue that touches memory (f32 residual in / out, activated
 // copy for the next layer).  The intermediate tensor never leaves the CU, and the HBM-bound tail of one block overlaps the
 // MFMA phases of the others.  A block owns all N = C output channels (NT = C / 64 column tiles per wave).
+// column tiles (of 64) per epilogue pass of the fused unit: two where the f32 staging tile then still fits beside the others
+constexpr int unit_pt(int MT, int NT) { return (NT % 2 == 0 && MT <= 4) ? 2 : 1; }
+
 template <typename T, int MT, int NT>
-__global__ __launch_bounds__(256) void conv_unit_kernel(const T* __restrict__ W1, const T* __restrict__ W2, int wpk, const T* __restrict__ X, int taps,
+__global__ __launch_bounds__(256, (NT == 3 && sizeof(T) == 2) ? 2 : 1) void conv_unit_kernel(const T* __restrict__ W1, const T* __restrict__ W2, int wpk, const T* __restrict__ X, int taps,
                                                         int dil, const float* __restrict__ bias1, const float* __restrict__ alpha2,
                                                         const float* __restrict__ den2, ConvEpi e) {
     using F = CFrag<T>;
@@ -408,10 +413,10 @@ __global__ __launch_bounds__(256) void conv_unit_kernel(const T* __restrict__ W1
     const long m0 = (long)blockIdx.x * RT;
     const int rows_t = RT + (taps - 1) * dil;
     const int K = taps * C, nC = taps * cpt;
-    const int tile_slots = (max(rows_t * vpr * 16, RT * (64 * (NT % 2 == 0 ? 2 : 1) + 4) * 4) + 1023) / 1024 * 64;
+    const int tile_slots = (max(rows_t * vpr * 16, RT * (64 * unit_pt(MT, NT) + 4) * 4) + 1023) / 1024 * 64;
     uint4* htile = tile + tile_slots;
     tile_load_dma<T>(tile, X + m0 * C, C, vpr, rows_t * vpr);
-    constexpr int PT = NT % 2 == 0 ? 2 : 1;
+    constexpr int PT = unit_pt(MT, NT);
     constexpr int CP = 64 * PT, OP = CP + 4, GPR = CP / 4;
     constexpr int EU = (RT / (256 / GPR) >= 8 ? 8 : RT / (256 / GPR));
     // prefetch the first pass's residual rows where that costs no occupancy (at NT = 2 it would take the third block off a CU)
@@ -545,13 +550,13 @@ __global__ __launch_bounds__(256) void conv_unit_kernel(const T* __restrict__ W1
 
 bool conv_unit_supported_fwd(int dtype, int C, int taps, int dil);
 
-template <typename T, int NT>
+template <typename T, int NT, int MT = 4>
 bool launch_unit(hipStream_t st, const T* W1, const T* W2, int wpk, const T* X, int taps, int dil, const float* bias1, const float* alpha2,
                  const float* den2, const ConvEpi& e) {
-    constexpr int MT = 4, RT = 64, C = 64 * NT, PT = NT % 2 == 0 ? 2 : 1;
+    constexpr int RT = 16 * MT, C = 64 * NT, PT = unit_pt(MT, NT);
     const size_t tile_b = (std::max((size_t)(RT + (taps - 1) * dil) * C * sizeof(T), (size_t)RT * (64 * PT + 4) * 4) + 1023) / 1024 * 1024;
     const size_t lds = tile_b + (size_t)RT * C * sizeof(T);
-    if (lds > (size_t)76 * 1024) return false;  // at least two blocks per CU
+    if (lds > (size_t)80 * 1024) return false;  // at least two blocks per CU
     if ((long)RT + (long)(taps - 1) * dil + 8 > CONV_HALO_SLACK) return false;
     const long gx = (e.M + RT - 1) / RT;
     if (gx > 0x7fffffffL) return false;
@@ -566,7 +571,14 @@ bool try_unit(hipStream_t st, const T* W1, const T* W2, int wpk, const T* X, int
               const float* den2, const ConvEpi& e) {
     if (e.N != C || e.r != 1 || !conv_unit_supported_fwd(sizeof(T) == 2 ? BF16 : F32, C, taps, dil)) return false;
     if (C == 64) return launch_unit<T, 1>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e);
-    if (C == 128) return launch_unit<T, 2>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e);
+    if (C == 128) {
+        // QTTS_UNIT_ROWS=128: 128-row tiles at 128 channels (every weight fragment feeds eight row tiles instead of four)
+        static const int rows = getenv("QTTS_UNIT_ROWS") ? atoi(getenv("QTTS_UNIT_ROWS")) : 64;
+        if constexpr (sizeof(T) == 2) {
+            if (rows == 128 && e.M >= 128L * 512 && launch_unit<T, 2, 8>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e)) return true;
+        }
+        return launch_unit<T, 2>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e);
+    }
     if (C == 192) return launch_unit<T, 3>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e);
     if constexpr (sizeof(T) == 2) {
         if (C == 256) return launch_unit<T, 4>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e);
