@@ -13,23 +13,32 @@ __device__ __forceinline__ float gelu_tanh(float v) {
     return 0.5f * v * (1.0f + tanhf(0.7978845608028654f * v * (1.0f + 0.044715f * v * v)));
 }
 
-// sin for SnakeBeta.  f32 runs keep the full-precision routine (bit-closeness to the reference's libm); bf16 runs use the
-// hardware sine after an explicit reduction to [0, 1) revolutions - its ~1e-6 absolute error is far below bf16 rounding.
+// SnakeBeta, x + sin^2(x e^alpha) / (e^beta + 1e-9), from the per-channel pair (al, dn) = (e^alpha, e^beta + 1e-9).
+// f32 runs keep the reference's arithmetic (full-precision sine, a division: bit-closeness to its libm).  bf16 runs evaluate
+// sin^2 t = (1 - cos 2t) / 2 with the hardware cosine on an argument reduced to [0, 1) revolutions: snake_prep turns the pair
+// into (e^alpha / pi, 0.5 / dn) once per channel, and an element then costs five instructions, one of them transcendental
+// (multiply, v_fract, v_cos, add, fma) instead of eight with two; the ~1e-6 absolute error is far below bf16 rounding.
 template <typename T>
-__device__ __forceinline__ float snake_sin(float x);
+__device__ __forceinline__ void snake_prep(float& al, float& dn);
 template <>
-__device__ __forceinline__ float snake_sin<float>(float x) { return sinf(x); }
+__device__ __forceinline__ void snake_prep<float>(float&, float&) {}
 template <>
-__device__ __forceinline__ float snake_sin<bf16_t>(float x) {
-    const float rev = x * 0.15915494309189535f;
-    return __builtin_amdgcn_sinf(rev - floorf(rev));
+__device__ __forceinline__ void snake_prep<bf16_t>(float& al, float& dn) {
+    al *= 0.3183098861837907f;
+    dn = 0.5f * __builtin_amdgcn_rcpf(dn);
 }
 template <typename T>
-__device__ __forceinline__ float snake_div(float a, float den);
+__device__ __forceinline__ float snake_apply(float x, float al, float dn);
 template <>
-__device__ __forceinline__ float snake_div<float>(float a, float den) { return a / den; }
+__device__ __forceinline__ float snake_apply<float>(float x, float al, float dn) {
+    const float sn = sinf(x * al);
+    return x + sn * sn / dn;
+}
 template <>
-__device__ __forceinline__ float snake_div<bf16_t>(float a, float den) { return a * __builtin_amdgcn_rcpf(den); }
+__device__ __forceinline__ float snake_apply<bf16_t>(float x, float al, float dn) {
+    const float c = __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(x * al));
+    return fmaf(-dn, c, x + dn);
+}
 
 __device__ __forceinline__ void ld4(const float* p, float (&o)[4]) {
     const float4 t = *reinterpret_cast<const float4*>(p);
@@ -43,7 +52,7 @@ __device__ __forceinline__ void ld4(const float* p, float (&o)[4]) {
 // stores (conv_epi_finish); conv_epi_apply is the three in a row.
 struct EpiCols {
     int j, co;
-    float bias[4], scale[4], al[4], den[4];
+    float bias[4], scale[4], al[4], den[4];  // al / den: SnakeBeta parameters as snake_prep leaves them
 };
 
 template <typename T>
@@ -58,6 +67,8 @@ __device__ __forceinline__ void conv_epi_cols(const ConvEpi& e, int n, EpiCols& 
     if (e.out2 && e.act2 != 1) {
         ld4(e.alpha_exp + c.co, c.al);
         ld4(e.beta_den + c.co, c.den);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) snake_prep<T>(c.al[q], c.den[q]);
     }
 }
 
@@ -135,8 +146,7 @@ __device__ __forceinline__ void conv_epi_finish(const ConvEpi& e, const EpiCols&
             // SnakeBeta in f32 on the value the next op would read: the stored (rounded) one unless the stream is kept in f32
             // or with its remainder
             const float x = (e.out_f32 || e.resid_f32 || e.out_lo || e.out2_lo) ? v[q] : to_f32<T>(from_f32<T>(v[q]));
-            const float sn = snake_sin<T>(x * c.al[q]);
-            store_split<T>(o + q, e.out2_lo, x + snake_div<T>(sn * sn, c.den[q]));
+            store_split<T>(o + q, e.out2_lo, snake_apply<T>(x, c.al[q], c.den[q]));
         }
     }
 }

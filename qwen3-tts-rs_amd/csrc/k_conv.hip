@@ -502,14 +502,15 @@ __global__ __launch_bounds__(256, (NT == 3 && sizeof(T) == 2) ? 2 : 1) void conv
         ld4(alpha2 + n, al);
         ld4(den2 + n, dn);
 #pragma unroll
+        for (int q = 0; q < 4; ++q) snake_prep<T>(al[q], dn[q]);
+#pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int row = 16 * i + r;
             T y[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float x = to_f32<T>(from_f32<T>(acc[i][j][q] + bs[q]));
-                const float sn = snake_sin<T>(x * al[q]);
-                y[q] = from_f32<T>(x + snake_div<T>(sn * sn, dn[q]));
+                y[q] = from_f32<T>(snake_apply<T>(x, al[q], dn[q]));
             }
             char* dst = reinterpret_cast<char*>(htile + row * vpr + ((n / VPE) ^ (row & 7))) + (n % VPE) * sizeof(T);
             __builtin_memcpy(dst, y, 4 * sizeof(T));
