@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
 // whatever the layer's width; the weight stream is prefetched across phase boundaries.
 template <typename T, int MT, int NT, int WN>
 __global__ __launch_bounds__(256, (MT * NT <= 32 && sizeof(T) == 2) ? 2 : 1) void conv_tile_kernel(const T* __restrict__ W, int wpk, const T* __restrict__ X, int K, int C, int taps, int dil,
-                                                        int cph, ConvEpi e) {
+                                                        int cph, long x_lo, ConvEpi e) {
     using F = CFrag<T>;
     extern __shared__ uint4 tile[];
     constexpr int WM = 4 / WN;
@@ -261,7 +261,9 @@ __global__ __launch_bounds__(256, (MT * NT <= 32 && sizeof(T) == 2) ? 2 : 1) voi
     const int vpr = cph / VPE;  // vectors per tile row (a multiple of 8)
     const int rows_t = RT + (taps - 1) * dil;
     const int nb = blockIdx.x * (16 * NT * WN);
-    const int cpp = cph / F::CHUNK, per_phase = taps * cpp, nC = (C / cph) * per_phase;
+    // x_lo != 0: X carries a remainder plane x_lo elements behind it (store_split); its phases follow the value plane's and
+    // meet the same weights, so the product sees the activations to about 16 significant bits
+    const int cpp = cph / F::CHUNK, per_phase = taps * cpp, nPh = C / cph, nC = (x_lo ? 2 : 1) * nPh * per_phase;
     f32x4_t acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 32 && sizeof(T) == 2) ? 2 : 1) voi
     auto woff = [&](int q) {
         const int ph = q / per_phase, rem = q - ph * per_phase;
         const int tap = rem / cpp, c = rem - tap * cpp;
-        return (tap * C + ph * cph) / F::CHUNK + c;
+        return (tap * C + (ph % nPh) * cph) / F::CHUNK + c;
     };
     {
         const int o = woff(0);
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 32 && sizeof(T) == 2) ? 2 : 1) voi
             const int ph = q / per_phase, rem = q - ph * per_phase;
             if (rem == 0) {  // new phase: its channels of the input tile
                 __syncthreads();
-                tile_load_dma<T>(tile, X + m0 * C + (size_t)ph * cph, C, vpr, rows_t * vpr);
+                tile_load_dma<T>(tile, X + (ph >= nPh ? x_lo : 0L) + m0 * C + (size_t)(ph % nPh) * cph, C, vpr, rows_t * vpr);
                 __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
                 __syncthreads();
             }
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 32 && sizeof(T) == 2) ? 2 : 1) voi
 }
 
 template <typename T, int MT, int NT, int WN>
-void launch_tile(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, int taps, int dil, int cph, const ConvEpi& e) {
+void launch_tile(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, int taps, int dil, int cph, long x_lo, const ConvEpi& e) {
     constexpr int RT = 16 * MT * (4 / WN);
     constexpr int PT = NT % 2 == 0 ? 2 : 1;
     const size_t lds = (std::max((size_t)(RT + (taps - 1) * dil) * cph * sizeof(T), (size_t)RT * (16 * WN * PT + 4) * 4) + 1023) / 1024 * 1024;
@@ -354,13 +356,13 @@ void launch_tile(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, 
     auto* fn = conv_tile_kernel<T, MT, NT, WN>;
     // the same ceiling from every caller: streams of several host threads launch this kernel with different tile sizes
     QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_CEILING));
-    hipLaunchKernelGGL(fn, dim3(e.N / (16 * NT * WN), (unsigned)gy), dim3(256), lds, st, W, wpk, X, K, C, taps, dil, cph, e);
+    hipLaunchKernelGGL(fn, dim3(e.N / (16 * NT * WN), (unsigned)gy), dim3(256), lds, st, W, wpk, X, K, C, taps, dil, cph, x_lo, e);
 }
 
 // 256 x 128 or 256 x 192 tiles.  The choice depends on the layer only, never on the number of rows: a row's result must not
 // depend on what else is in the batch (the two kernels walk K in different orders).
 template <typename T>
-bool try_tile(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, int taps, int dil, const ConvEpi& e) {
+bool try_tile(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, int taps, int dil, const ConvEpi& e, long x_lo = 0) {
     static const bool off = getenv("QTTS_CONV_TILE2") && atoi(getenv("QTTS_CONV_TILE2")) == 0;
     static const long min_rows = getenv("QTTS_CONV_TILE2_ROWS") ? atol(getenv("QTTS_CONV_TILE2_ROWS")) : 1;
     static const long min_k = getenv("QTTS_CONV_TILE2_K") ? atol(getenv("QTTS_CONV_TILE2_K")) : 2600;
@@ -369,7 +371,7 @@ bool try_tile(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, int
     // only wins where the K walk is long
     // (measured on the vocoder: wins for 7-tap convs over >= 384 channels, for the wide two-tap transposed convs, and where the
     // halo of a dilated conv would push the other kernel's tile past 64 KB; no gain on anything narrower or on 1x1 convs)
-    const bool long_k = (long)taps * C >= min_k;
+    const bool long_k = (long)taps * C * (x_lo ? 2 : 1) >= min_k;  // (a remainder plane doubles the K walk)
     const bool wide_ct = taps == 2 && (long)taps * C >= 1536 && e.N >= 1920;
     const bool big_halo = (size_t)(64 + halo) * C * sizeof(T) > (size_t)64 * 1024;
     if (off || e.M < min_rows || halo > 128 || 256 + halo + 8 > CONV_HALO_SLACK || (e.M + 255) / 256 > 0x7fffffffL ||
@@ -382,8 +384,8 @@ bool try_tile(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, int
     for (int c = C; c >= 64; c -= 64)
         if (C % c == 0 && (size_t)(256 + halo) * c * sizeof(T) <= tile_cap) { cph = c; break; }
     if (cph == 0) return false;
-    if (e.N % 128 == 0) launch_tile<T, 8, 4, 2>(st, W, wpk, X, K, C, taps, dil, cph, e);
-    else if (e.N % 192 == 0) launch_tile<T, 8, 6, 2>(st, W, wpk, X, K, C, taps, dil, cph, e);
+    if (e.N % 128 == 0) launch_tile<T, 8, 4, 2>(st, W, wpk, X, K, C, taps, dil, cph, x_lo, e);
+    else if (e.N % 192 == 0) launch_tile<T, 8, 6, 2>(st, W, wpk, X, K, C, taps, dil, cph, x_lo, e);
     else return false;
     return true;
 }
@@ -629,7 +631,7 @@ bool try_halo(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, int
 
 // Returns false when the shape does not fit the LDS-tile kernel (the caller then uses the tap-addressed GEMM).
 // X rows must be contiguous (row stride == channels per tap) and readable for 256 rows + the halo past e.M.
-bool launch_conv_halo(hipStream_t st, int dtype, WMat Wm, const void* X, int K, int ldx, int taps, long tap_stride, const ConvEpi& e) {
+bool launch_conv_halo(hipStream_t st, int dtype, WMat Wm, const void* X, int K, int ldx, int taps, long tap_stride, const ConvEpi& e, long x_lo) {
     const void* W = Wm.p;
     const int wpk = Wm.packed ? 1 : 0;
     if (taps < 1 || K % taps != 0) return false;
@@ -639,8 +641,12 @@ bool launch_conv_halo(hipStream_t st, int dtype, WMat Wm, const void* X, int K, 
     if (taps > 1 && (tap_stride <= 0 || tap_stride % ldx != 0)) return false;
     const long dil = taps > 1 ? tap_stride / ldx : 1;
     if (dil < 1 || dil > 64) return false;
+    // QTTS_CONV_TILE_LO=0: inputs with a remainder plane through the tap-addressed GEMM, as before the wave-grid kernel walked them
+    static const bool lo_off = getenv("QTTS_CONV_TILE_LO") && atoi(getenv("QTTS_CONV_TILE_LO")) == 0;
+    if (x_lo != 0 && (dtype != BF16 || lo_off)) return false;
     if (dtype == BF16) {
-        if (try_tile<bf16_t>(st, (const bf16_t*)W, wpk, (const bf16_t*)X, K, C, taps, (int)dil, e)) return true;
+        if (try_tile<bf16_t>(st, (const bf16_t*)W, wpk, (const bf16_t*)X, K, C, taps, (int)dil, e, x_lo)) return true;
+        if (x_lo != 0) return false;  // only the wave-grid kernel walks a remainder plane
         return try_halo<bf16_t>(st, (const bf16_t*)W, wpk, (const bf16_t*)X, K, C, taps, (int)dil, e);
     }
     if (try_tile<float>(st, (const float*)W, wpk, (const float*)X, K, C, taps, (int)dil, e)) return true;

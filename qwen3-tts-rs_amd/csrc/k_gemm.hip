@@ -479,7 +479,7 @@ void launch_gemm_rows_epi(hipStream_t st, int dtype, WMat Wm, const void* X, int
     const int chunk = dtype == BF16 ? 64 : 32;
     QTTS_CHECK((K / taps) % chunk == 0, ERR_SHAPE, "gemm_rows: channels per tap must be a multiple of the K chunk");
     QTTS_CHECK(x_lo == 0 || dtype == BF16, ERR_BAD_ARG, "gemm_rows: a remainder plane exists for bf16 activations only");
-    if (x_lo == 0 && !gemm_env().conv_halo_off && launch_conv_halo(st, dtype, Wm, X, K, ldx, taps, tap_stride, e)) return;
+    if (!gemm_env().conv_halo_off && launch_conv_halo(st, dtype, Wm, X, K, ldx, taps, tap_stride, e, x_lo)) return;
     const long Mpad = (M + 63) / 64 * 64;
     const int cpt = K / taps / chunk;
     if (dtype == BF16 && x_lo) launch_rows_t<bf16_t, true, true>(st, (const bf16_t*)W, wpk, (const bf16_t*)X, nullptr, Mpad, N, K, ldx, cpt, tap_stride, e, x_lo);

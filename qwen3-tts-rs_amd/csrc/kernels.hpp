@@ -261,7 +261,9 @@ void launch_gemm_rows_epi(hipStream_t st, int dtype, WMat W, const void* X, int 
 // X must be readable for CONV_HALO_SLACK rows past e.M: the last block's tile starts below e.M and spans its rows, the halo of
 // the taps and up to 8 rows of DMA rounding; a shape whose tile would reach further is refused (false).
 constexpr long CONV_HALO_SLACK = 448;
-bool launch_conv_halo(hipStream_t st, int dtype, WMat W, const void* X, int K, int ldx, int taps, long tap_stride, const ConvEpi& e);
+// x_lo != 0 (bf16): X carries a remainder plane (see launch_gemm); covered by the wave-grid tile kernel only
+bool launch_conv_halo(hipStream_t st, int dtype, WMat W, const void* X, int K, int ldx, int taps, long tap_stride, const ConvEpi& e,
+                      long x_lo = 0);
 bool conv_unit_supported(int dtype, int C, int taps, int dil);
 bool launch_conv_unit(hipStream_t st, int dtype, WMat W1, WMat W2, const void* X, int C, int taps, int dil, const float* bias1,
                       const float* alpha2, const float* den2, const ConvEpi& e);
