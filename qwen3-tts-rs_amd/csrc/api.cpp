@@ -6,6 +6,7 @@
 #include <thread>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "generate.hpp"
 
@@ -49,6 +50,26 @@ extern "C" {
 
 const char* qtts_last_error(void) { return g_err.c_str(); }
 
+// Experiment switch QTTS_STREAM_PARTS=n (2..8): stream number k of the process (context streams and session streams in creation
+// order) is confined to the compute units whose index is k modulo n, so that n streams never queue for each other's CUs.
+static hipError_t create_stream(hipStream_t* st) {
+    static const int parts = getenv("QTTS_STREAM_PARTS") ? atoi(getenv("QTTS_STREAM_PARTS")) : 0;
+    static std::atomic<int> created{0};
+    if (parts < 2 || parts > 8) return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    const int k = created.fetch_add(1) % parts;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return e;
+    const int ncu = prop.multiProcessorCount;
+    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    for (int i = 0; i < ncu; ++i)
+        if (i % parts == k) mask[(size_t)i / 32] |= 1u << (i % 32);
+    return hipExtStreamCreateWithCUMask(st, (uint32_t)mask.size(), mask.data());
+}
+
 int qtts_init(int device_ordinal, qtts_ctx** out) {
     QTTS_API_BEGIN
     QTTS_CHECK(out != nullptr, ERR_BAD_ARG, "qtts_init: null out");
@@ -62,7 +83,7 @@ int qtts_init(int device_ordinal, qtts_ctx** out) {
                std::string("qtts_init: kernels are built for gfx950 only, found ") + prop.gcnArchName);
     std::unique_ptr<qtts_ctx> c(new qtts_ctx());
     c->c.device = device_ordinal;
-    QTTS_HIP(hipStreamCreateWithFlags(&c->c.stream, hipStreamNonBlocking));
+    QTTS_HIP(create_stream(&c->c.stream));
     (void)mel_scratch(device_ordinal);  // device address of this GPU's fixed staging array (qtts_mel_noalloc)
     *out = c.release();
     QTTS_API_END
@@ -128,7 +149,7 @@ int qtts_session_open(qtts_model* base, qtts_model** out) {
     s->own_ctx.reset(new Ctx());
     s->own_ctx->device = base->m.ctx->device;
     QTTS_HIP(hipSetDevice(s->own_ctx->device));
-    QTTS_HIP(hipStreamCreateWithFlags(&s->own_ctx->stream, hipStreamNonBlocking));
+    QTTS_HIP(create_stream(&s->own_ctx->stream));
     s->m.ctx = s->own_ctx.get();
     try {
         s->m.init_view(base->m);
