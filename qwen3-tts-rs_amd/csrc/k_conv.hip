@@ -68,6 +68,31 @@ __device__ __forceinline__ void tile_load_dma(uint4* tile, const T* src, int C, 
     }
 }
 
+// Block -> tile map of the conv kernels.  The grid is one-dimensional and a multiple of 8 long; blocks are handed to the eight
+// XCDs round-robin, so block b works on tile p = (b % 8) * (grid / 8) + b / 8: consecutive tiles - the column blocks of one row
+// block, then the next row block - run on ONE XCD and find the input rows they share (the same tile for every column block, the
+// halo of a neighbouring row block) in its L2 instead of fetching them once per XCD.  Placement is a matter of speed only: any
+// other hand-out of the blocks computes the same result.  xcd == 0: tile p = b.  False: the block has no tile.
+__device__ __forceinline__ bool conv_block_tile(long total, int ncol, int xcd, int& colb, long& rowb) {
+    const long b = blockIdx.x;
+    const long p = xcd ? (b & 7) * ((long)gridDim.x >> 3) + (b >> 3) : b;
+    if (p >= total) return false;
+    rowb = p / ncol;
+    colb = (int)(p - rowb * ncol);
+    return true;
+}
+// grid length for `total` tiles (false: too many for one launch)
+static bool conv_grid(long total, int xcd, unsigned& grid) {
+    const long g = xcd ? (total + 7) / 8 * 8 : total;
+    if (g < 1 || g > 0x7ffffff8L) return false;
+    grid = (unsigned)g;
+    return true;
+}
+static int conv_xcd_order() {  // QTTS_CONV_XCD=0: tiles in launch order
+    static const int on = getenv("QTTS_CONV_XCD") ? (atoi(getenv("QTTS_CONV_XCD")) != 0) : 1;
+    return on;
+}
+
 // One epilogue pass over the transposed accumulators in LDS: RT rows x 4 * GPR columns starting at column n0.  A thread keeps
 // the same four columns for every row it visits, so the column parameters are loaded once, and the residual loads of
 // up to eight rows are issued before the first of them is needed.
@@ -150,20 +175,23 @@ __device__ __forceinline__ void epi_rows_finish(const ConvEpi& e, const EpiCols&
 
 template <typename T, int MT, int NT>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W, int wpk, const T* __restrict__ X, int K, int C, int taps, int dil,
-                                                        ConvEpi e) {
+                                                        int xcd, ConvEpi e) {
     using F = CFrag<T>;
     extern __shared__ uint4 tile[];
     constexpr int RT = 16 * MT;
     constexpr int VPE = 16 / (int)sizeof(T);  // elements per 16-byte vector
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const long m0 = (long)blockIdx.y * RT;
+    int colb;
+    long rowb;
+    if (!conv_block_tile((e.M + RT - 1) / RT * (e.N / (64 * NT)), e.N / (64 * NT), xcd, colb, rowb)) return;
+    const long m0 = rowb * RT;
     const int vpr = C / VPE;  // vectors per row (a multiple of 8)
     const int rows_t = RT + (taps - 1) * dil;
     tile_load_dma<T>(tile, X + m0 * C, C, vpr, rows_t * vpr);
     // wave w owns the 16-column tiles 4 j + w of the block's 64 NT columns (interleaved, so that an epilogue pass over
     // tiles j .. j + PT - 1 of every wave covers one contiguous run of columns)
-    const int nb = blockIdx.x * (64 * NT);
+    const int nb = colb * (64 * NT);
     const int cpt = C / F::CHUNK, nC = taps * cpt;
     f32x4_t acc[MT][NT];
 #pragma unroll
@@ -248,7 +276,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
 // whatever the layer's width; the weight stream is prefetched across phase boundaries.
 template <typename T, int MT, int NT, int WN>
 __global__ __launch_bounds__(256, (MT * NT <= 32 && sizeof(T) == 2) ? 2 : 1) void conv_tile_kernel(const T* __restrict__ W, int wpk, const T* __restrict__ X, int K, int C, int taps, int dil,
-                                                        int cph, long x_lo, ConvEpi e) {
+                                                        int cph, long x_lo, int xcd, ConvEpi e) {
     using F = CFrag<T>;
     extern __shared__ uint4 tile[];
     constexpr int WM = 4 / WN;
@@ -257,10 +285,13 @@ __global__ __launch_bounds__(256, (MT * NT <= 32 && sizeof(T) == 2) ? 2 : 1) voi
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int wm = wave / WN, wn = wave - wm * WN;
-    const long m0 = (long)blockIdx.y * RT;
+    int colb;
+    long rowb;
+    if (!conv_block_tile((e.M + RT - 1) / RT * (e.N / (16 * NT * WN)), e.N / (16 * NT * WN), xcd, colb, rowb)) return;
+    const long m0 = rowb * RT;
     const int vpr = cph / VPE;  // vectors per tile row (a multiple of 8)
     const int rows_t = RT + (taps - 1) * dil;
-    const int nb = blockIdx.x * (16 * NT * WN);
+    const int nb = colb * (16 * NT * WN);
     // x_lo != 0: X carries a remainder plane x_lo elements behind it (store_split); its phases follow the value plane's and
     // meet the same weights, so the product sees the activations to about 16 significant bits
     const int cpp = cph / F::CHUNK, per_phase = taps * cpp, nPh = C / cph, nC = (x_lo ? 2 : 1) * nPh * per_phase;
@@ -353,10 +384,13 @@ void launch_tile(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, 
     constexpr int PT = NT % 2 == 0 ? 2 : 1;
     const size_t lds = (std::max((size_t)(RT + (taps - 1) * dil) * cph * sizeof(T), (size_t)RT * (16 * WN * PT + 4) * 4) + 1023) / 1024 * 1024;
     const long gy = (e.M + RT - 1) / RT;
+    const int xcd = conv_xcd_order();
+    unsigned grid = 0;
+    QTTS_CHECK(conv_grid(gy * (e.N / (16 * NT * WN)), xcd, grid), ERR_SHAPE, "conv: too many tiles for one launch");
     auto* fn = conv_tile_kernel<T, MT, NT, WN>;
     // the same ceiling from every caller: streams of several host threads launch this kernel with different tile sizes
     QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_CEILING));
-    hipLaunchKernelGGL(fn, dim3(e.N / (16 * NT * WN), (unsigned)gy), dim3(256), lds, st, W, wpk, X, K, C, taps, dil, cph, x_lo, e);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, st, W, wpk, X, K, C, taps, dil, cph, x_lo, xcd, e);
 }
 
 // 256 x 128 or 256 x 192 tiles.  The choice depends on the layer only, never on the number of rows: a row's result must not
@@ -402,7 +436,7 @@ constexpr int unit_pt(int MT, int NT) { return (NT % 2 == 0 && MT <= 4) ? 2 : 1;
 template <typename T, int MT, int NT>
 __global__ __launch_bounds__(256, (NT == 3 && sizeof(T) == 2) ? 2 : 1) void conv_unit_kernel(const T* __restrict__ W1, const T* __restrict__ W2, int wpk, const T* __restrict__ X, int taps,
                                                         int dil, const float* __restrict__ bias1, const float* __restrict__ alpha2,
-                                                        const float* __restrict__ den2, ConvEpi e) {
+                                                        const float* __restrict__ den2, int xcd, ConvEpi e) {
     using F = CFrag<T>;
     extern __shared__ uint4 tile[];
     constexpr int RT = 16 * MT;
@@ -412,7 +446,10 @@ __global__ __launch_bounds__(256, (NT == 3 && sizeof(T) == 2) ? 2 : 1) void conv
     constexpr int cpt = C / F::CHUNK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const long m0 = (long)blockIdx.x * RT;
+    int colb;
+    long rowb;
+    if (!conv_block_tile((e.M + RT - 1) / RT, 1, xcd, colb, rowb)) return;
+    const long m0 = rowb * RT;
     const int rows_t = RT + (taps - 1) * dil;
     const int K = taps * C, nC = taps * cpt;
     const int tile_slots = (max(rows_t * vpr * 16, RT * (64 * unit_pt(MT, NT) + 4) * 4) + 1023) / 1024 * 64;
@@ -562,10 +599,12 @@ bool launch_unit(hipStream_t st, const T* W1, const T* W2, int wpk, const T* X, 
     if (lds > (size_t)80 * 1024) return false;  // at least two blocks per CU
     if ((long)RT + (long)(taps - 1) * dil + 8 > CONV_HALO_SLACK) return false;
     const long gx = (e.M + RT - 1) / RT;
-    if (gx > 0x7fffffffL) return false;
+    const int xcd = conv_xcd_order();
+    unsigned grid = 0;
+    if (!conv_grid(gx, xcd, grid)) return false;
     auto* fn = conv_unit_kernel<T, MT, NT>;
     QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_CEILING));
-    hipLaunchKernelGGL(fn, dim3((unsigned)gx), dim3(256), lds, st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, xcd, e);
     return true;
 }
 
@@ -593,7 +632,10 @@ template <typename T, int MT, int NT>
 void launch_halo(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, int taps, int dil, const ConvEpi& e, size_t lds) {
     const long RT = 16 * MT;
     const long gy = (e.M + RT - 1) / RT;
-    hipLaunchKernelGGL((conv_halo_kernel<T, MT, NT>), dim3(e.N / (64 * NT), (unsigned)gy), dim3(256), lds, st, W, wpk, X, K, C, taps, dil, e);
+    const int xcd = conv_xcd_order();
+    unsigned grid = 0;
+    QTTS_CHECK(conv_grid(gy * (e.N / (64 * NT)), xcd, grid), ERR_SHAPE, "conv: too many tiles for one launch");
+    hipLaunchKernelGGL((conv_halo_kernel<T, MT, NT>), dim3(grid), dim3(256), lds, st, W, wpk, X, K, C, taps, dil, xcd, e);
 }
 
 template <typename T>

@@ -396,11 +396,12 @@ class Model:
         B, T, Q = c.shape
         lens_a = np.ascontiguousarray(lens if lens is not None else [T] * B, np.int32)
         stride = (T + 1) * self.total_upsample()
-        wav = np.zeros((B, stride), np.float32)
+        wav = np.empty((B, stride), np.float32)   # rows are valid up to wl[b]; nothing past that is handed out
         wl = np.zeros(B, np.int64)
         check(self.lib.qtts_codec_decode(self._m, c.ctypes.data_as(C.c_void_p), lens_a.ctypes.data_as(C.c_void_p), B, T, chunk,
                                          left_ctx, wav.ctypes.data_as(C.c_void_p), stride, wl.ctypes.data_as(C.c_void_p)))
-        return [wav[b, :wl[b]].copy() for b in range(B)]
+        # views of the one host buffer the library filled (a second pass over a batch's waveforms costs tens of milliseconds)
+        return [wav[b, :wl[b]] for b in range(B)]
 
     def decode_output(self, output: Output):
         """Model::decode_output (model/generate.rs:29-143): truncate to effective lengths, chunk long sequences."""
