@@ -374,8 +374,15 @@ def main():
             fl = synth.codec_flops_per_frame(ccfg) * sum(out_last[0].effective_lengths)
             peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
             ach = fl / (iso_ms * 1e-3) / 1e12
+            # HBM-side bytes of the decode from the PMC counters (tools/dev/pmc_codec.sh: 16 x 375 frames, scaled by the frames
+            # decoded here: every stage's traffic is proportional to them), quoted for the shapes the passes were taken on
+            ctraffic = None
+            cpath = os.path.join(ROOT, "bench_data", "r02_codec_traffic.json")   # a copy lives under profiles/
+            if os.path.exists(cpath) and args.shape == "S17" and args.dtype == "bf16":
+                ct = json.load(open(cpath))
+                ctraffic = round(ct["traffic_bytes"] * sum(out_last[0].effective_lengths) / float(ct["batch"] * ct["frames"]))
             codec = {"bound": "mfma", "kernel": "codec decoder, one batch alone on the GPU (conv / transposed-conv implicit GEMMs with fused epilogues)",
-                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                     "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": ctraffic,
                      "device_ms_isolated": round(iso_ms, 2), "device_ms_per_step_overlapped": round(stats["codec_ms"] / args.steps, 2)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
