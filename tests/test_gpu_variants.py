@@ -37,10 +37,10 @@ print("variant ok")
 
 @pytest.mark.parametrize("env", [{"QTTS_CONV_HALO": "0"}, {"QTTS_CONV_TILE": "3"}, {"QTTS_GEMM_KIND": "0"},
                                  {"QTTS_CONV_TILE2_K": "0"}, {"QTTS_CONV_TILE2": "0"}, {"QTTS_CONV_UNIT": "0"}, {"QTTS_ROWS_MIN_M": "17"}, {"QTTS_GEMM_MIN_BLOCKS": "448"},
-                                 {"QTTS_ATTN_TILES": "0"}],
+                                 {"QTTS_ATTN_TILES": "0"}, {"QTTS_CONV_XCD": "0"}],
                          ids=["tap-gemm-conv", "wide-conv-tiles", "in-block-split-k-gemm", "wave-grid-conv-everywhere",
                               "no-wave-grid-conv", "unfused-residual-units", "large-m-gemm-from-17-rows", "more-split-k-slabs",
-                              "per-token-prefill-attention"])
+                              "per-token-prefill-attention", "conv-tiles-in-launch-order"])
 def test_variant_matches_golden(env):
     e = dict(os.environ, **env)
     r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + SCRIPT], env=e, capture_output=True, text=True, timeout=280)
