@@ -18,7 +18,9 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
+#include <string>
 
 namespace qtts {
 
@@ -675,7 +677,22 @@ bool gemm_stream_fits(int M, int N, int K, bool lo) {
 bool gemm_stream_preferred(int M, int N, int K, bool lo) {
     static const int mode = getenv("QTTS_GEMM_STREAM") ? atoi(getenv("QTTS_GEMM_STREAM")) : 1;
     if (mode == 0 || !gemm_stream_fits(M, N, K, lo)) return false;
-    return mode >= 2 || (K == 2048 && N >= 8192);
+    if (mode >= 2) return true;
+    // several streams in flight: wherever it fits (see tuning_shared in kernels.hpp; in the whole job that beats keeping the
+    // whole-K tile for the code predictor's q|k|v and heads, 2000 against 1954 audio-s/s without the codec)
+    if (tuning_shared()) return true;
+    return K == 2048 && N >= 8192;
+}
+
+static std::atomic<int> g_open_sessions{0};
+void tuning_sessions_changed(int delta) { g_open_sessions.fetch_add(delta); }
+bool tuning_shared() {
+    static const int forced = [] {
+        const char* v = getenv("QTTS_TUNE");
+        if (!v) return -1;
+        return std::string(v) == "shared" ? 1 : (std::string(v) == "alone" ? 0 : -1);
+    }();
+    return forced >= 0 ? forced == 1 : g_open_sessions.load() > 0;
 }
 
 template <int MODE, bool LO, int NP>
@@ -732,8 +749,10 @@ void launch_gemm_k_split(hipStream_t st, WMat Wm, const void* X, int ldx, long x
     dim3 grid(N / 16, rows / 16);
     const int planes = x_lo ? 2 : 1;
     const int per_wave = (K / CHUNK + KS_WAVES - 1) / KS_WAVES;          // chunks of the longest wave slice
-    static const int group_env = getenv("QTTS_KS_GROUP") ? atoi(getenv("QTTS_KS_GROUP")) : KS_GROUP;
-    const int group = std::max(planes, std::min(KS_GROUP, group_env));
+    // X chunks a wave requests at once: six alone on the GPU, three with several decode streams in flight (56 instead of 104 KB of
+    // LDS per block: blocks of two streams share a CU)
+    static const int group_env = getenv("QTTS_KS_GROUP") ? atoi(getenv("QTTS_KS_GROUP")) : 0;
+    const int group = std::max(planes, std::min(KS_GROUP, group_env > 0 ? group_env : (tuning_shared() ? 3 : KS_GROUP)));
     const int gcap = std::max(1, std::min(group / planes, per_wave));
     const size_t lds = (size_t)KS_WAVES * 64 * 16 + (size_t)KS_WAVES * planes * gcap * 2048;
     if (x_lo) {

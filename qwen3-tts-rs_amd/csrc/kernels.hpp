@@ -55,6 +55,18 @@ void launch_gemm(hipStream_t st, int dtype, WMat W, const void* X, float* out, i
 void launch_gemm_rows(hipStream_t st, int dtype, WMat W, const void* X, float* out, long M, int N, int K, int ldx, int taps,
                       long tap_stride, long x_lo = 0);
 
+// ---- decode kernel choice for one stream alone on the GPU or several in flight (k_gemm_fused.hip)
+// With several decode streams on one GPU (sessions) the kernels queue for each other's CUs, and what counts is a kernel's
+// throughput next to copies of itself, not its latency alone.  Measured with tools/gemm_harness on one and on three streams
+// (us per launch overall, 64 rows): talker q|k|v 4096 x 2048 - whole-K tile 10.1 / 8.75, K-streaming kernel 12.8 / 5.16;
+// code-predictor gate|up 6144 x 1024 - 7.1 / 3.82 against 7.8 / 3.08; k_split at K = 3072 with six X chunks per request
+// 6.0 / 3.78, with three 6.2 / 2.75.  In the whole three-session job: 1832 audio-s/s (no codec) with the kernels picked for one
+// stream, 2000 with the K-streaming kernel wherever it fits and three chunks per k_split request.  tuning_shared() is true while a session of any model is open (QTTS_TUNE=alone / shared
+// forces it); the pickers below read it at launch time, i.e. when a generate call captures its frame graph.  Results of bf16 runs
+// differ between the two choices by summation order only (same bounds against the oracle); f32 runs do not use these kernels.
+void tuning_sessions_changed(int delta);
+bool tuning_shared();
+
 // ---- k_gemm_fused.hip: decode GEMMs that own finished outputs and apply the consumer's element-wise work (bf16, hidden <= 1024)
 enum { FUSED_PLAIN = 0, FUSED_SWIGLU = 1, FUSED_RESID = 2 };
 struct FusedEpi {

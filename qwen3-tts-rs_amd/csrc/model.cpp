@@ -9,7 +9,9 @@
 namespace qtts {
 
 Model::Model() = default;
-Model::~Model() = default;
+Model::~Model() {
+    if (is_view && finalized) tuning_sessions_changed(-1);
+}
 
 static StackCfg stack_from(const Json& j, int def_layers, int def_inter, int def_nkv) {
     StackCfg s;
@@ -356,6 +358,7 @@ void Model::init_view(const Model& base) {
         ensure_rope(cp, 64);
     }
     finalized = true;
+    tuning_sessions_changed(+1);  // decode kernels are picked for several streams in flight from now on
 }
 
 void Model::finalize() {

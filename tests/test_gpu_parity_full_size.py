@@ -113,16 +113,22 @@ def test_headline_shape_f32_rows_of_a_batch_of_64():
         m.close()
 
 
-def test_headline_shape_bf16_logits_of_a_batch_of_64():
+@pytest.mark.parametrize("with_session", [False, True], ids=["one-stream-kernels", "several-streams-kernels"])
+def test_headline_shape_bf16_logits_of_a_batch_of_64(with_session):
     """The benchmarked configuration itself (1.7B-like, bf16, 64 rows): logits of rows 0, 31 and 63 within max-abs 2e-2 of
-    the oracle on the same bf16-rounded weights for as long as the code histories agree (at least the first frame)."""
+    the oracle on the same bf16-rounded weights for as long as the code histories agree (at least the first frame).
+    With a session open the decode kernels are the ones picked for several streams in flight (the benchmark's case): the run
+    then goes through the session's handle."""
     from oracle import bind
-    m, o, cfg, ccfg, tmpl = _pair(bind, "S17", "bf16")
+    base, o, cfg, ccfg, tmpl = _pair(bind, "S17", "bf16")
+    m = base.open_session() if with_session else base
     try:
         frames = 8
         texts, reqs = _batch64(tmpl)
         out = m.generate(reqs, _greedy(), frames, trace=True)
         alone = {b: m.generate([reqs[b]], _greedy(), frames, trace=True) for b in (0, 31, 63)}
+        if with_session:   # the captured frame graph of the same kernels reproduces the kernel-by-kernel launches
+            assert np.array_equal(m.generate(reqs, _greedy(), frames).codes, out.codes)
         for b in (0, 31, 63):
             ref = _oracle_row(bind, o, cfg, texts[b], frames)
             same = (ref["codes"] == out.codes[b]).all(axis=1)
@@ -142,7 +148,9 @@ def test_headline_shape_bf16_logits_of_a_batch_of_64():
                 cerr = np.abs(ol[:nj] - out.cp_logits[b][t][:nj]).max()
                 assert cerr <= BF16_LOGIT_TOL, f"row {b} frame {t}: code-predictor logits {cerr:.4f} over {nj} codebooks"
     finally:
-        m.close()
+        if with_session:
+            m.close()
+        base.close()
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
