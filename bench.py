@@ -237,7 +237,13 @@ def main():
         stream_first = not args.no_codec and 2 < args.first_frames < args.frames
         out = mod.generate(reqs, sampling, args.frames, use_graph=not args.no_graph, first_frames=args.first_frames if stream_first else 0,
                            on_first_chunk=on_first if stream_first else None, min_new_tokens=0 if args.natural_eos else args.frames)
+        t_g = time.perf_counter()
         wavs = [] if args.no_codec else mod.decode_output(out)
+        if record and os.environ.get("QTTS_BENCH_TIMING"):   # where a step's wall time goes beyond the device phases (stderr)
+            t_d = time.perf_counter()
+            print(f"step: generate wall {(t_g - t_s) * 1e3:.1f} ms (device prefill {mod.last_timing['prefill_ms']:.1f} + frames "
+                  f"{mod.last_timing['frames_ms']:.1f}), first-chunk callback at {first_ms[0] if first_ms else 0:.1f} ms, "
+                  f"decode wall {(t_d - t_g) * 1e3:.1f} ms (device {0.0 if args.no_codec else mod.codec_device_ms():.1f})", file=sys.stderr)
         if record:
             with lock:
                 stats["prefill_ms"] += mod.last_timing["prefill_ms"]

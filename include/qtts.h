@@ -65,9 +65,10 @@ void qtts_model_free(qtts_model* m);
  * exists once.  The handle is a qtts_model handle: every entry point below that takes a qtts_model* (generate, codec decode
  * and streaming decode, mel, speaker embedding, audio encoding, timing, info) accepts it and runs on the session's stream;
  * qtts_model_load_tensor* and qtts_model_finalize fail on it.  Sessions of one model may be driven from different host
- * threads (one thread per session); the codec decoder, speaker encoder and codec encoder keep one set of workspaces per
- * model, so calls into each of them are serialised across sessions.  Close every session before qtts_model_free of the
- * model it was opened on. */
+ * threads (one thread per session); the codec decoder's buffers belong to the handle too (codec decodes of several sessions run
+ * side by side; up to QTTS_CODEC_SCRATCH_MB, default 32 GiB, each), while the speaker encoder and the codec encoder keep one set
+ * of workspaces per model, so calls into each of them are serialised across sessions.  Close every session before
+ * qtts_model_free of the model it was opened on. */
 typedef qtts_model qtts_session;
 int qtts_session_open(qtts_model* m, qtts_session** out);
 void qtts_session_close(qtts_session* s);

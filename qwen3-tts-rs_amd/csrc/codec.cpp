@@ -46,10 +46,30 @@ struct CodecState {
     float final_b = 0.f;
     int final_CP = 0;
     int maxpad = 0;  // leading zero rows of the strips inside the vocoder blocks
-    // run-time buffers (grown on demand, kept between calls)
+};
+
+// Run-time buffers of the decoder (grown on demand, kept between calls).  Every model handle - the model itself and each of its
+// sessions - owns a set, so that the codec decodes of several sessions run side by side instead of queueing for one workspace
+// (a session that had to wait for another one's decode left its stream idle for up to a whole decode).  A handle is driven by
+// one host thread at a time, so no lock is needed.  xf is a view of the transformer's weights with RoPE tables of its own.
+struct CodecScratch {
     Workspace ws;
+    StackW xf;
     DevBuf kv, toks, tiles, meta, codes, A, Bf, R, Rf, acc, wav;
 };
+
+static CodecScratch& codec_scratch(Model& m) {
+    if (!m.codec_scratch) {
+        auto w = std::make_shared<CodecScratch>();
+        const StackW& b = m.codec_state->xf;
+        w->xf.cfg = b.cfg;
+        w->xf.layers = b.layers;
+        w->xf.final_norm = b.final_norm;
+        w->xf.max_pos = 0;  // RoPE tables grow on demand, per handle
+        m.codec_scratch = w;
+    }
+    return *m.codec_scratch;
+}
 
 // Streaming decode session: the transformer's keys/values live in a ring per row, and the last `ctx_cap` frames of codes and
 // of transformer output are kept so that the convolutional stack of the next push sees real history instead of zero padding.
@@ -250,12 +270,14 @@ Geometry make_geometry(const CodecCfg& c, const CodecState& s, int U, int Tm) {
 
 struct Decoder {
     Model& m;
-    CodecState& s;
+    CodecState& s;     // weights
+    CodecScratch& w;   // this handle's buffers
     hipStream_t st;
     int dt;
     size_t es;
 
-    explicit Decoder(Model& model) : m(model), s(*model.codec_state), st(model.ctx->stream), dt(model.dtype), es(dtype_size(model.dtype)) {}
+    explicit Decoder(Model& model)
+        : m(model), s(*model.codec_state), w(codec_scratch(model)), st(model.ctx->stream), dt(model.dtype), es(dtype_size(model.dtype)) {}
 
     // A conv is issued in two steps so that the call sites read like the reference's forward(): gemm() names the
     // weights and the input view, epilogue() launches the GEMM with that element-wise tail applied in registers.
@@ -347,10 +369,10 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         for (auto& v : t) v -= 1;
         o_lenm1[(size_t)i] = push(t);
     }
-    s.meta.ensure(meta.size() * 4);
-    QTTS_HIP(hipMemcpyAsync(s.meta.p, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, st));
+    w.meta.ensure(meta.size() * 4);
+    QTTS_HIP(hipMemcpyAsync(w.meta.p, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, st));
     QTTS_HIP(hipStreamSynchronize(st));  // `meta` is a local
-    const int* d_meta = s.meta.as<int>();
+    const int* d_meta = w.meta.as<int>();
     auto d_len = [&](int i) { return d_meta + o_len[(size_t)i]; };
     auto d_lenm1 = [&](int i) { return d_meta + o_lenm1[(size_t)i]; };
 
@@ -368,30 +390,30 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
                 QTTS_HIP(hipMemset2DAsync((char*)buf + (size_t)lo * es, (size_t)S_rows * C * es, 0, (size_t)P_rows * C * es, (size_t)U, st));
         }
     };
-    s.A.ensure((g.act_elems + (lo ? g.lo_elems : 0)) * es);
-    s.Bf.ensure((g.act_elems + (lo ? g.lo_elems : 0)) * es);
-    s.R.ensure((g.act_elems + (lo ? g.lo_elems : 0)) * es);
-    s.Rf.ensure(g.res_elems * 4);  // the vocoder's residual stream is kept in f32
-    s.acc.ensure(g.acc_elems * 4);
-    s.wav.ensure((size_t)U * (size_t)g.wav_max * 4);
+    w.A.ensure((g.act_elems + (lo ? g.lo_elems : 0)) * es);
+    w.Bf.ensure((g.act_elems + (lo ? g.lo_elems : 0)) * es);
+    w.R.ensure((g.act_elems + (lo ? g.lo_elems : 0)) * es);
+    w.Rf.ensure(g.res_elems * 4);  // the vocoder's residual stream is kept in f32
+    w.acc.ensure(g.acc_elems * 4);
+    w.wav.ensure((size_t)U * (size_t)g.wav_max * 4);
 
     ScopedEvent ev0, ev1;
     QTTS_HIP(hipEventRecord(ev0, st));
     // ================= stage 0: RVQ lookup -> pre_conv -> transformer =================
     const long M0 = U * S[0];
     const int Hd = c.hidden;
-    QTTS_HIP(hipMemsetAsync(s.A.p, 0, (size_t)(M0 + SLACK_ROWS) * s.DcP * es, st));
-    if (lo) QTTS_HIP(hipMemsetAsync((char*)s.A.p + (size_t)lo * es, 0, (size_t)(M0 + SLACK_ROWS) * s.DcP * es, st));
+    QTTS_HIP(hipMemsetAsync(w.A.p, 0, (size_t)(M0 + SLACK_ROWS) * s.DcP * es, st));
+    if (lo) QTTS_HIP(hipMemsetAsync((char*)w.A.p + (size_t)lo * es, 0, (size_t)(M0 + SLACK_ROWS) * s.DcP * es, st));
     launch_rvq_gather(st, dt, s.table.as<float>(), d_codes, d_meta + o_rows, d_meta + o_starts, d_len(0), U, Tm, s.Q, s.csize, s.DcP,
-                      T_max, S[0], P[0], s.A.p, s.DcP, lo);
+                      T_max, S[0], P[0], w.A.p, s.DcP, lo);
     // pre_conv (k = 3): acc row (u, t) reads strip rows t .. t + 2 (two leading zero rows)
-    gemm(s.pre_conv, s.A.p, M0, s.DcP, lo);
-    QTTS_HIP(hipMemsetAsync(s.Bf.p, 0, (size_t)(M0 + SLACK_ROWS) * s.latP * es, st));
-    if (lo) QTTS_HIP(hipMemsetAsync((char*)s.Bf.p + (size_t)lo * es, 0, (size_t)(M0 + SLACK_ROWS) * s.latP * es, st));
+    gemm(s.pre_conv, w.A.p, M0, s.DcP, lo);
+    QTTS_HIP(hipMemsetAsync(w.Bf.p, 0, (size_t)(M0 + SLACK_ROWS) * s.latP * es, st));
+    if (lo) QTTS_HIP(hipMemsetAsync((char*)w.Bf.p + (size_t)lo * es, 0, (size_t)(M0 + SLACK_ROWS) * s.latP * es, st));
     {
         ConvEpi e{};
         e.M = M0; e.N = s.pre_conv.N; e.r = 1; e.Cout = s.pre_conv.CoutP; e.bias = s.pre_conv.bias.as<float>();
-        e.lens = d_len(0); e.S_in = S[0]; e.S_out = S[0]; e.P_out = 0; e.ld_out = s.latP; e.out = s.Bf.p; e.out_lo = lo;
+        e.lens = d_len(0); e.S_in = S[0]; e.S_out = S[0]; e.P_out = 0; e.ld_out = s.latP; e.out = w.Bf.p; e.out_lo = lo;
         epilogue(e);
     }
     // transformer over every strip row (rows past a strip's length are computed and ignored)
@@ -401,10 +423,10 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         const size_t rp = (size_t)gemm_pad_rows(M) + 64;
         const int nqkv = (c.heads + 2 * c.kv_heads) * c.head_dim, nq = c.heads * c.head_dim;
         const int Nmax = std::max({nqkv, 2 * c.inter, Hd, s.latP});
-        s.ws.x.ensure(rp * Hd * 4);
-        s.ws.alloc_inputs(rp, (size_t)Hd, (size_t)nq, (size_t)c.inter, es, split_activations(dt));
-        s.ws.part.ensure((size_t)Nmax * std::max(rp, (size_t)GEMM_MAX_KS * std::min<size_t>(rp, 512)) * 4);
-        s.ws.q.ensure(rp * nq * 4);
+        w.ws.x.ensure(rp * Hd * 4);
+        w.ws.alloc_inputs(rp, (size_t)Hd, (size_t)nq, (size_t)c.inter, es, split_activations(dt));
+        w.ws.part.ensure((size_t)Nmax * std::max(rp, (size_t)GEMM_MAX_KS * std::min<size_t>(rp, 512)) * 4);
+        w.ws.q.ensure(rp * nq * 4);
         // pages: one private range per strip + one shared dump page for the padding rows
         const int pp = sc ? sc->ring_pages : (Tm + PAGE - 1) / PAGE;
         // a streaming push holds C context frames in front of the new ones: only the new frames are tokens, at the
@@ -424,54 +446,54 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
                 }
             }
         const size_t page_elems = (size_t)2 * c.kv_heads * PAGE * c.head_dim;
-        if (!sc) s.kv.ensure(((size_t)U + 1) * pp * page_elems * es);  // row U: dump pages for the padding rows
-        s.toks.ensure(toks.size() * sizeof(Tok));
-        QTTS_HIP(hipMemcpyAsync(s.toks.p, toks.data(), toks.size() * sizeof(Tok), hipMemcpyHostToDevice, st));
+        if (!sc) w.kv.ensure(((size_t)U + 1) * pp * page_elems * es);  // row U: dump pages for the padding rows
+        w.toks.ensure(toks.size() * sizeof(Tok));
+        QTTS_HIP(hipMemcpyAsync(w.toks.p, toks.data(), toks.size() * sizeof(Tok), hipMemcpyHostToDevice, st));
         // the strips' rows are runs of consecutive positions: banded attention in tiles of up to 64 queries on the matrix cores
         std::vector<AttnTile> tiles;
         build_attn_tiles(toks.data(), M, tiles);
-        s.tiles.ensure(tiles.size() * sizeof(AttnTile));
-        QTTS_HIP(hipMemcpyAsync(s.tiles.p, tiles.data(), tiles.size() * sizeof(AttnTile), hipMemcpyHostToDevice, st));
+        w.tiles.ensure(tiles.size() * sizeof(AttnTile));
+        QTTS_HIP(hipMemcpyAsync(w.tiles.p, tiles.data(), tiles.size() * sizeof(AttnTile), hipMemcpyHostToDevice, st));
         QTTS_HIP(hipStreamSynchronize(st));  // toks and tiles are locals
         // one-shot decodes reuse one layer's worth of pages for every layer; a session keeps all layers
-        KVView kv{s.kv.p, 0, PAGE, c.kv_heads, c.head_dim, pp, nullptr};
+        KVView kv{w.kv.p, 0, PAGE, c.kv_heads, c.head_dim, pp, nullptr};
         if (sc) {
             kv.base = sc->kv.p;
             kv.layer_stride = ((size_t)U + 1) * pp * page_elems;
             kv.page_mask = pp - 1;
         }
         const int pos_end = (int)(pos0 + Tm);
-        if (s.xf.max_pos < std::max(pos_end, PAGE)) {
+        if (w.xf.max_pos < std::max(pos_end, PAGE)) {
             int n = 256;
             while (n < pos_end) n *= 2;
             std::vector<float> cs, sn;
             rope_table_simple(c.head_dim, c.rope_theta, n, cs, sn);
-            s.xf.cos.alloc(cs.size() * 4);
-            s.xf.sin.alloc(sn.size() * 4);
-            copy_sync(s.xf.cos.p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice, m.ctx->stream);
-            copy_sync(s.xf.sin.p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice, m.ctx->stream);
-            s.xf.max_pos = n;
+            w.xf.cos.alloc(cs.size() * 4);
+            w.xf.sin.alloc(sn.size() * 4);
+            copy_sync(w.xf.cos.p, cs.data(), cs.size() * 4, hipMemcpyHostToDevice, m.ctx->stream);
+            copy_sync(w.xf.sin.p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice, m.ctx->stream);
+            w.xf.max_pos = n;
         }
-        Runner run(m, s.ws, nullptr);
-        run.tiles = s.tiles.as<AttnTile>();
+        Runner run(m, w.ws, nullptr);
+        run.tiles = w.tiles.as<AttnTile>();
         run.n_tiles = (int)tiles.size();
         // input_proj (+bias) starts the residual stream
         int ks = run.ks_for(M, Hd, s.latP);
-        run.gemm(s.in_proj.wm(), s.Bf.p, M, Hd, s.latP, ks, s.latP, lo);
-        launch_resid_norm(st, dt, nullptr, s.ws.part.as<float>(), ks, run.kstride(M, Hd), s.in_proj.bias.as<float>(), nullptr,
-                          s.xf.layers[0].ln1, c.eps, s.ws.x.as<float>(), s.ws.xn.p, nullptr, M, Hd, s.ws.lo_xn);
-        run.stack(s.xf, M, s.toks.as<Tok>(), kv, s.ws.xn.p, nullptr, sc != nullptr, false, s.ws.lo_xn);
+        run.gemm(s.in_proj.wm(), w.Bf.p, M, Hd, s.latP, ks, s.latP, lo);
+        launch_resid_norm(st, dt, nullptr, w.ws.part.as<float>(), ks, run.kstride(M, Hd), s.in_proj.bias.as<float>(), nullptr,
+                          w.xf.layers[0].ln1, c.eps, w.ws.x.as<float>(), w.ws.xn.p, nullptr, M, Hd, w.ws.lo_xn);
+        run.stack(w.xf, M, w.toks.as<Tok>(), kv, w.ws.xn.p, nullptr, sc != nullptr, false, w.ws.lo_xn);
         // output_proj (+bias) -> strips without padding (the next op is a kernel == stride transposed conv)
         ks = run.ks_for(M, s.latP, Hd);
-        run.gemm(s.out_proj.wm(), s.ws.xn.p, M, s.latP, Hd, ks, Hd, s.ws.lo_xn);
-        const float* acc = s.ws.part.as<float>();
+        run.gemm(s.out_proj.wm(), w.ws.xn.p, M, s.latP, Hd, ks, Hd, w.ws.lo_xn);
+        const float* acc = w.ws.part.as<float>();
         if (ks != 1) {  // fold the split-K slabs so that the conv epilogue sees one [M][N] matrix
-            launch_bias_act(st, s.ws.part.as<float>(), ks, run.kstride(M, s.latP), nullptr, 0, s.acc.p, F32, M, s.latP);
-            acc = s.acc.as<float>();
+            launch_bias_act(st, w.ws.part.as<float>(), ks, run.kstride(M, s.latP), nullptr, 0, w.acc.p, F32, M, s.latP);
+            acc = w.acc.as<float>();
         }
         ConvEpi e{};
         e.acc = acc; e.M = M0; e.N = s.latP; e.r = 1; e.Cout = s.latP; e.bias = s.out_proj.bias.as<float>();
-        e.lens = d_len(0); e.S_in = S[0]; e.S_out = S[0]; e.P_out = 0; e.ld_out = s.latP; e.out = s.A.p; e.out_lo = lo;
+        e.lens = d_len(0); e.S_in = S[0]; e.S_out = S[0]; e.P_out = 0; e.ld_out = s.latP; e.out = w.A.p; e.out_lo = lo;
         launch_conv_epilogue(st, dt, e);
         if (sc) {
             // rows [0, C) of every strip: the transformer output of the previous pushes; then keep this push's tail
@@ -479,7 +501,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
             const int keep = std::min(Tm, sc->ctx_cap);
             // the session's copy holds both planes of a split tensor, the second one sc->B * slot bytes behind the first
             for (int pl = 0; pl < (lo ? 2 : 1); ++pl) {
-                char* a = (char*)s.A.p + (size_t)pl * lo * es;
+                char* a = (char*)w.A.p + (size_t)pl * lo * es;
                 char* ctx = (char*)sc->latent_ctx.p + (size_t)pl * sc->B * slot;
                 if (Cs > 0) QTTS_HIP(hipMemcpy2DAsync(a, strip, ctx, slot, (size_t)Cs * rowb, (size_t)U, hipMemcpyDeviceToDevice, st));
                 QTTS_HIP(hipMemcpy2DAsync(ctx, slot, a + (size_t)(Tm - keep) * rowb, strip, (size_t)keep * rowb, (size_t)U, hipMemcpyDeviceToDevice, st));
@@ -493,34 +515,34 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         const long Min = U * S[(size_t)i], Mout = U * S[(size_t)i + 1];
         const int Pn = P[(size_t)i + 1];
         // transposed conv (kernel == stride): A -> R (strips with six leading zero rows for the depthwise conv)
-        gemm(up.ct, (const char*)s.A.p + (size_t)Pcur * s.latP * es, Min, s.latP, lo);
-        zero_pad_rows(s.R.p, S[(size_t)i + 1], Pn, s.latP, true);
+        gemm(up.ct, (const char*)w.A.p + (size_t)Pcur * s.latP * es, Min, s.latP, lo);
+        zero_pad_rows(w.R.p, S[(size_t)i + 1], Pn, s.latP, true);
         {
             ConvEpi e{};
             e.M = Min; e.N = up.ct.N; e.r = up.ct.r; e.Cout = up.ct.CoutP; e.bias = up.ct.bias.as<float>();
-            e.lens = d_len(i); e.S_in = S[(size_t)i]; e.S_out = S[(size_t)i + 1]; e.P_out = Pn; e.ld_out = s.latP; e.out = s.R.p; e.out_lo = lo;
+            e.lens = d_len(i); e.S_in = S[(size_t)i]; e.S_out = S[(size_t)i + 1]; e.P_out = Pn; e.ld_out = s.latP; e.out = w.R.p; e.out_lo = lo;
             epilogue(e);
         }
         // ConvNeXt: depthwise conv + LayerNorm -> A ; pwconv1 + GELU -> Bf ; pwconv2 * gamma + residual -> R (in place)
-        launch_dwconv_ln(st, dt, s.R.p, up.dw_w.as<float>(), up.dw_b.as<float>(), up.ln_w.as<float>(), up.ln_b.as<float>(), d_len(i + 1), U,
-                         (int)g.Tmax[(size_t)i + 1], S[(size_t)i + 1], Pn, s.latP, s.A.p, lo);
-        gemm(up.pw1, (const char*)s.A.p + (size_t)Pn * s.latP * es, Mout, s.latP);
+        launch_dwconv_ln(st, dt, w.R.p, up.dw_w.as<float>(), up.dw_b.as<float>(), up.ln_w.as<float>(), up.ln_b.as<float>(), d_len(i + 1), U,
+                         (int)g.Tmax[(size_t)i + 1], S[(size_t)i + 1], Pn, s.latP, w.A.p, lo);
+        gemm(up.pw1, (const char*)w.A.p + (size_t)Pn * s.latP * es, Mout, s.latP);
         {
             ConvEpi e{};
             e.M = Mout; e.N = up.pw1.N; e.r = 1; e.Cout = up.pw1.CoutP; e.bias = up.pw1.bias.as<float>();
             e.act = 1; e.lens = d_len(i + 1); e.S_in = S[(size_t)i + 1]; e.S_out = S[(size_t)i + 1]; e.P_out = 0; e.ld_out = up.pw1.CoutP;
-            e.out = s.Bf.p;
+            e.out = w.Bf.p;
             epilogue(e);
         }
-        gemm(up.pw2, s.Bf.p, Mout, up.pw1.CoutP);
+        gemm(up.pw2, w.Bf.p, Mout, up.pw1.CoutP);
         {
             ConvEpi e{};
             e.M = Mout; e.N = up.pw2.N; e.r = 1; e.Cout = up.pw2.CoutP; e.bias = up.pw2.bias.as<float>();
-            e.scale = up.gamma.as<float>(); e.resid = s.R.p; e.lens = d_len(i + 1); e.S_in = S[(size_t)i + 1]; e.S_out = S[(size_t)i + 1];
-            e.P_out = Pn; e.ld_out = s.latP; e.out = s.R.p; e.resid_lo = lo; e.out_lo = lo;
+            e.scale = up.gamma.as<float>(); e.resid = w.R.p; e.lens = d_len(i + 1); e.S_in = S[(size_t)i + 1]; e.S_out = S[(size_t)i + 1];
+            e.P_out = Pn; e.ld_out = s.latP; e.out = w.R.p; e.resid_lo = lo; e.out_lo = lo;
             epilogue(e);
         }
-        std::swap(s.A, s.R);  // the stage's result becomes the current tensor
+        std::swap(w.A, w.R);  // the stage's result becomes the current tensor
         Pcur = Pn;
     }
     // ================= vocoder =================
@@ -529,18 +551,18 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
     {
         // decoder.0 (k = 7): A -> snake(block 1 .0) in Bf; the raw result is not needed again
         const long M = U * S[(size_t)nup];
-        gemm(s.dec0, (const char*)s.A.p + (size_t)(Pcur - 6) * s.latP * es, M, s.latP, lo);
+        gemm(s.dec0, (const char*)w.A.p + (size_t)(Pcur - 6) * s.latP * es, M, s.latP, lo);
         ConvEpi e{};
         e.M = M; e.N = s.dec0.N; e.r = 1; e.Cout = CP; e.bias = s.dec0.bias.as<float>();
         e.lens = d_len(nup); e.S_in = S[(size_t)nup]; e.S_out = S[(size_t)nup]; e.P_out = 0; e.ld_out = CP;
-        e.out2 = s.Bf.p; e.alpha_exp = s.blocks[0].s0.a.as<float>(); e.beta_den = s.blocks[0].s0.den.as<float>();
+        e.out2 = w.Bf.p; e.alpha_exp = s.blocks[0].s0.a.as<float>(); e.beta_den = s.blocks[0].s0.den.as<float>();
         e.out2_lo = lo;
         epilogue(e);
     }
     // Inside a block R is the residual stream and A the activated input of the next conv, both with maxpad leading
     // zero rows per strip.  `xin` is the activated input of the block's transposed conv: Bf for the first block,
     // afterwards the previous block's A viewed from its first valid row.
-    const char* xin = (const char*)s.Bf.p;
+    const char* xin = (const char*)w.Bf.p;
     for (int b = 0; b < nb; ++b) {
         const CodecState::Block& blk = s.blocks[(size_t)b];
         const int si = nup + b, so = si + 1;
@@ -548,12 +570,12 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         const int Pn = P[(size_t)so];
         const int CPo = blk.ct.CoutP;
         gemm(blk.ct, xin, Min, CP, b < SPLIT_BLOCKS ? lo : 0);
-        zero_pad_rows(s.A.p, S[(size_t)so], Pn, CPo);
+        zero_pad_rows(w.A.p, S[(size_t)so], Pn, CPo);
         {
             ConvEpi e{};
             e.M = Min; e.N = blk.ct.N; e.r = blk.ct.r; e.Cout = CPo; e.bias = blk.ct.bias.as<float>();
             e.lens = d_lenm1(si); e.S_in = S[(size_t)si]; e.S_out = S[(size_t)so]; e.P_out = Pn; e.ld_out = CPo;
-            e.out_f32 = s.Rf.as<float>(); e.out2 = s.A.p; e.alpha_exp = blk.u[0].a1.a.as<float>(); e.beta_den = blk.u[0].a1.den.as<float>();
+            e.out_f32 = w.Rf.as<float>(); e.out2 = w.A.p; e.alpha_exp = blk.u[0].a1.a.as<float>(); e.beta_den = blk.u[0].a1.den.as<float>();
             epilogue(e);
         }
         // Residual units.  Where the fused kernel covers the block's width, each unit is one launch that reads the activated
@@ -562,17 +584,17 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         bool fuse = true;
         for (int u = 0; u < 3; ++u) fuse = fuse && conv_unit_supported(dt, CPo, blk.u[u].c1.taps, blk.u[u].c1.dil);
         if (fuse) {
-            zero_pad_rows(s.Bf.p, S[(size_t)so], Pn, CPo);
-            DevBuf* in = &s.A;
-            DevBuf* outb = &s.Bf;
+            zero_pad_rows(w.Bf.p, S[(size_t)so], Pn, CPo);
+            DevBuf* in = &w.A;
+            DevBuf* outb = &w.Bf;
             for (int u = 0; u < 3; ++u) {
                 const CodecState::Unit& un = blk.u[u];
                 ConvEpi e{};
                 e.M = Mout; e.N = CPo; e.r = 1; e.Cout = CPo; e.bias = un.c2.bias.as<float>();
-                e.resid_f32 = s.Rf.as<float>(); e.lens = d_len(so); e.S_in = S[(size_t)so]; e.S_out = S[(size_t)so]; e.P_out = Pn; e.ld_out = CPo;
+                e.resid_f32 = w.Rf.as<float>(); e.lens = d_len(so); e.S_in = S[(size_t)so]; e.S_out = S[(size_t)so]; e.P_out = Pn; e.ld_out = CPo;
                 const Snake& nx = u < 2 ? blk.u[u + 1].a1 : (b + 1 < nb ? s.blocks[(size_t)b + 1].s0 : s.sfinal);
                 e.alpha_exp = nx.a.as<float>(); e.beta_den = nx.den.as<float>();
-                e.out_f32 = u < 2 ? s.Rf.as<float>() : nullptr;
+                e.out_f32 = u < 2 ? w.Rf.as<float>() : nullptr;
                 e.out2 = outb->p;
                 e.out2_lo = (u == 2 && b + 1 < SPLIT_BLOCKS) ? lo : 0;
                 Prof pr{};
@@ -591,29 +613,29 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
                 }
                 std::swap(in, outb);
             }
-            std::swap(s.A, s.Bf);  // three units: the block's result sits in the other buffer; A names it again
+            std::swap(w.A, w.Bf);  // three units: the block's result sits in the other buffer; A names it again
         }
         for (int u = 0; u < 3 && !fuse; ++u) {
             const CodecState::Unit& un = blk.u[u];
             // conv1 (k = 7, dilated): A -> snake(act2) in Bf
-            gemm(un.c1, (const char*)s.A.p + (size_t)(Pn - 6 * un.c1.dil) * CPo * es, Mout, CPo);
+            gemm(un.c1, (const char*)w.A.p + (size_t)(Pn - 6 * un.c1.dil) * CPo * es, Mout, CPo);
             {
                 ConvEpi e{};
                 e.M = Mout; e.N = CPo; e.r = 1; e.Cout = CPo; e.bias = un.c1.bias.as<float>();
                 e.lens = d_len(so); e.S_in = S[(size_t)so]; e.S_out = S[(size_t)so]; e.P_out = 0; e.ld_out = CPo;
-                e.out2 = s.Bf.p; e.alpha_exp = un.a2.a.as<float>(); e.beta_den = un.a2.den.as<float>();
+                e.out2 = w.Bf.p; e.alpha_exp = un.a2.a.as<float>(); e.beta_den = un.a2.den.as<float>();
                 epilogue(e);
             }
             // conv2 (k = 1) + residual: R += conv2(Bf); A = snake_next(R).  After the last unit the raw sum is dead.
-            gemm(un.c2, s.Bf.p, Mout, CPo);
+            gemm(un.c2, w.Bf.p, Mout, CPo);
             {
                 ConvEpi e{};
                 e.M = Mout; e.N = CPo; e.r = 1; e.Cout = CPo; e.bias = un.c2.bias.as<float>();
-                e.resid_f32 = s.Rf.as<float>(); e.lens = d_len(so); e.S_in = S[(size_t)so]; e.S_out = S[(size_t)so]; e.P_out = Pn; e.ld_out = CPo;
+                e.resid_f32 = w.Rf.as<float>(); e.lens = d_len(so); e.S_in = S[(size_t)so]; e.S_out = S[(size_t)so]; e.P_out = Pn; e.ld_out = CPo;
                 const Snake& nx = u < 2 ? blk.u[u + 1].a1 : (b + 1 < nb ? s.blocks[(size_t)b + 1].s0 : s.sfinal);
                 e.alpha_exp = nx.a.as<float>(); e.beta_den = nx.den.as<float>();
-                e.out_f32 = u < 2 ? s.Rf.as<float>() : nullptr;  // after the last unit only the activated copy is read again
-                e.out2 = s.A.p;
+                e.out_f32 = u < 2 ? w.Rf.as<float>() : nullptr;  // after the last unit only the activated copy is read again
+                e.out2 = w.A.p;
                 e.out2_lo = (u == 2 && b + 1 < SPLIT_BLOCKS) ? lo : 0;
                 epilogue(e);
             }
@@ -622,14 +644,14 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         if (b + 1 < nb) {
             // the next block overwrites A and R only after its transposed-conv GEMM has consumed xin, but its epilogue
             // writes A while nothing reads it any more; Bf takes over as the activation buffer to keep xin intact
-            std::swap(s.A, s.Bf);
-            xin = (const char*)s.Bf.p + (size_t)Pn * CP * es;
+            std::swap(w.A, w.Bf);
+            xin = (const char*)w.Bf.p + (size_t)Pn * CP * es;
         }
     }
     // ================= final conv (C -> 1, k = 7) + clamp =================
     const int last = nstage - 1;
-    launch_final_conv(st, dt, s.A.p, s.final_w.as<float>(), s.final_b, d_len(last), U, g.Tmax[(size_t)last], S[(size_t)last], P[(size_t)last],
-                      s.final_CP, s.wav.as<float>(), g.wav_max);
+    launch_final_conv(st, dt, w.A.p, s.final_w.as<float>(), s.final_b, d_len(last), U, g.Tmax[(size_t)last], S[(size_t)last], P[(size_t)last],
+                      s.final_CP, w.wav.as<float>(), g.wav_max);
     QTTS_HIP(hipEventRecord(ev1, st));
     const long up_total = c.total_upsample();
     for (int u = 0; u < U; ++u) {
@@ -641,7 +663,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         QTTS_CHECK(n >= 0, ERR_SHAPE, "codec decode: chunk shorter than its context");
         QTTS_CHECK(p.out_off + n <= wav_stride, ERR_SHAPE, "codec decode: wav_stride too small");
         if (n > 0)
-            QTTS_HIP(hipMemcpyAsync(wav_out + (size_t)p.row * wav_stride + p.out_off, s.wav.as<float>() + (size_t)u * g.wav_max + drop,
+            QTTS_HIP(hipMemcpyAsync(wav_out + (size_t)p.row * wav_stride + p.out_off, w.wav.as<float>() + (size_t)u * g.wav_max + drop,
                                     (size_t)n * 4, hipMemcpyDeviceToHost, st));
     }
     QTTS_HIP(hipStreamSynchronize(st));
@@ -656,12 +678,12 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
 // Model::decode_output / TokenizerV2::{decode, chunked_decode} (model/generate.rs:29-143, audio/decoder/v2.rs:163-286).
 void run_codec_decode(Model& m, const uint32_t* codes, const int* lens, int B, int T_max, int chunk, int left_ctx, float* wav_out,
                       int64_t wav_stride, int64_t* wav_lens) {
-    std::lock_guard<std::mutex> lock(m.locks->codec);  // sessions of one model share the decoder's workspaces
     QTTS_CHECK(m.finalized && m.codec_state, ERR_STATE, "codec weights are not loaded");
     QTTS_CHECK(B >= 1 && T_max >= 1 && wav_stride >= 1, ERR_BAD_ARG, "codec decode: bad batch shape");
     QTTS_CHECK(chunk == -2 || chunk <= 0 || left_ctx >= 0, ERR_BAD_ARG, "codec decode: negative left context");
     QTTS_HIP(hipSetDevice(m.ctx->device));
     CodecState& s = *m.codec_state;
+    CodecScratch& w = codec_scratch(m);
     const CodecCfg& c = m.codec;
     const long up_total = c.total_upsample();
     // every code id is validated on the host (quantizer lookups index device tables with them)
@@ -708,8 +730,8 @@ void run_codec_decode(Model& m, const uint32_t* codes, const int* lens, int B, i
     m.timing[6] = 0;
     if (pieces.empty()) return;
     std::stable_sort(pieces.begin(), pieces.end(), [](const Piece& a, const Piece& b) { return a.len > b.len; });
-    s.codes.ensure((size_t)B * T_max * s.Q * 4);
-    copy_sync(s.codes.p, codes, (size_t)B * T_max * s.Q * 4, hipMemcpyHostToDevice, m.ctx->stream);
+    w.codes.ensure((size_t)B * T_max * s.Q * 4);
+    copy_sync(w.codes.p, codes, (size_t)B * T_max * s.Q * 4, hipMemcpyHostToDevice, m.ctx->stream);
     // ---- groups bounded by a scratch budget
     static const size_t budget = (size_t)(getenv("QTTS_CODEC_SCRATCH_MB") ? std::max(64, atoi(getenv("QTTS_CODEC_SCRATCH_MB"))) : 32768) << 20;
     Decoder dec(m);
@@ -719,7 +741,7 @@ void run_codec_decode(Model& m, const uint32_t* codes, const int* lens, int B, i
         size_t n = 1;
         while (i + n < pieces.size() && n < 4096 && make_geometry(c, s, (int)n + 1, Tm).bytes(dec.es) <= budget) ++n;
         std::vector<Piece> grp(pieces.begin() + (long)i, pieces.begin() + (long)(i + n));
-        dec.run_group(s.codes.as<uint32_t>(), T_max, grp, wav_out, wav_stride);
+        dec.run_group(w.codes.as<uint32_t>(), T_max, grp, wav_out, wav_stride);
         i += n;
     }
 }
@@ -750,7 +772,6 @@ static int conv_context_frames(const CodecCfg& c) {
 }
 
 CodecStream* codec_stream_open(Model& m, int B, int max_chunk) {
-    std::lock_guard<std::mutex> lock(m.locks->codec);
     QTTS_CHECK(m.finalized && m.codec_state, ERR_STATE, "codec weights are not loaded");
     QTTS_CHECK(B >= 1 && B <= 4096 && max_chunk >= 1 && max_chunk <= 8192, ERR_BAD_ARG, "codec stream: bad batch or chunk size");
     QTTS_HIP(hipSetDevice(m.ctx->device));
@@ -783,11 +804,11 @@ void codec_stream_close(CodecStream* sc) {
 // up * n - tail for the first push, up * n afterwards; *n_samples is that count.
 void codec_stream_push(CodecStream& sc, const uint32_t* codes, int n, float* wav_out, int64_t wav_stride, int64_t* n_samples) {
     Model& m = *sc.m;
-    std::lock_guard<std::mutex> lock(m.locks->codec);
     QTTS_CHECK(m.finalized && m.codec_state, ERR_STATE, "codec weights are not loaded");
     QTTS_CHECK(n >= 1 && n <= sc.max_chunk, ERR_BAD_ARG, "codec stream: push is empty or longer than the session's max_chunk");
     QTTS_HIP(hipSetDevice(m.ctx->device));
     CodecState& s = *m.codec_state;
+    CodecScratch& w = codec_scratch(m);
     const CodecCfg& c = m.codec;
     const int B = sc.B, Q = s.Q, C = sc.C, T = C + n;
     for (size_t i = 0; i < (size_t)B * n * Q; ++i) QTTS_CHECK(codes[i] < (uint32_t)s.csize, ERR_BAD_ARG, "codec stream: code id out of range");
@@ -807,13 +828,13 @@ void codec_stream_push(CodecStream& sc, const uint32_t* codes, int n, float* wav
         if (C > 0) std::memcpy(dst, &sc.ctx_codes[(size_t)b * C * Q], (size_t)C * Q * 4);
         std::memcpy(dst + (size_t)C * Q, codes + (size_t)b * n * Q, (size_t)n * Q * 4);
     }
-    s.codes.ensure(all.size() * 4);
-    copy_sync(s.codes.p, all.data(), all.size() * 4, hipMemcpyHostToDevice, m.ctx->stream);
+    w.codes.ensure(all.size() * 4);
+    copy_sync(w.codes.p, all.data(), all.size() * 4, hipMemcpyHostToDevice, m.ctx->stream);
     std::vector<Piece> ps;
     for (int b = 0; b < B; ++b) ps.push_back(Piece{b, 0, T, 0, 0});
     m.timing[6] = 0;
     Decoder dec(m);
-    dec.run_group(s.codes.as<uint32_t>(), T, ps, wav_out, wav_stride, &sc);
+    dec.run_group(w.codes.as<uint32_t>(), T, ps, wav_out, wav_stride, &sc);
     // session state for the next push
     const int Cn = std::min(T, sc.ctx_cap);
     std::vector<uint32_t> ctx((size_t)B * Cn * Q);

@@ -117,15 +117,16 @@ struct StackW {
 
 struct Model;
 struct GenState;    // generate.cpp
-struct CodecState;  // codec.cpp
+struct CodecState;    // codec.cpp: the decoder's weights (shared by the sessions of a model)
+struct CodecScratch;  // codec.cpp: its run-time buffers (one set per model handle, session or not)
 struct SpeakerState;
 struct EncoderState;  // encoder.cpp
 
-// The codec decoder, the speaker encoder and the codec encoder keep their weights and their workspaces in one state object
-// each; sessions of one model share those objects, so calls into them are serialised (a call returns only when its result is
-// on the host, so the workspaces are free again when the lock is released).
+// The speaker encoder and the codec encoder keep their weights and their workspaces in one state object each; sessions of one
+// model share those objects, so calls into them are serialised (a call returns only when its result is on the host, so the
+// workspaces are free again when the lock is released).  The codec decoder's buffers belong to the handle (CodecScratch).
 struct SharedLocks {
-    std::mutex codec, speaker, encoder;
+    std::mutex speaker, encoder;
 };
 
 // Code-predictor passes 1 .. groups - 2 start from the embedding row of the code just drawn.  What the first layer makes of such a
@@ -159,6 +160,7 @@ struct Model {
     DevBuf cp_emb_ptrs;                    // device array of G-1 table pointers
     std::shared_ptr<GenState> gen;
     std::shared_ptr<CodecState> codec_state;
+    std::shared_ptr<CodecScratch> codec_scratch;  // created by the handle's first codec call
     std::shared_ptr<SpeakerState> spk_state;
     std::shared_ptr<EncoderState> enc_state;
     double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
