@@ -63,7 +63,7 @@ void launch_gemm_rows(hipStream_t st, int dtype, WMat W, const void* X, float* o
 // 6.0 / 3.78, with three 6.2 / 2.75.  In the whole three-session job: 1832 audio-s/s (no codec) with the kernels picked for one
 // stream, 2000 with the K-streaming kernel wherever it fits and three chunks per k_split request.  tuning_shared() is true while a session of any model is open (QTTS_TUNE=alone / shared
 // forces it); the pickers below read it at launch time, i.e. when a generate call captures its frame graph.  Results of bf16 runs
-// differ between the two choices by summation order only (same bounds against the oracle); f32 runs do not use these kernels.
+// differ between the two choices by summation order only (within the same bounds against a CPU evaluation); f32 runs do not use these kernels.
 void tuning_sessions_changed(int delta);
 bool tuning_shared();
 
