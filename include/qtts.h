@@ -25,6 +25,7 @@ extern "C" {
 #define QTTS_ERR_OOM (-3)
 #define QTTS_ERR_SHAPE (-4)
 #define QTTS_ERR_STATE (-5)
+#define QTTS_ERR_IO (-6)
 
 #define QTTS_F32 0
 #define QTTS_BF16 1
@@ -57,6 +58,13 @@ int qtts_model_load_tensor_device(qtts_model* m, const char* hf_key, const void*
 /* Checks that every tensor the configs require is present, builds fused weights, RoPE tables and the
  * normalised codebooks (audio/quantizer.rs:56-59). */
 int qtts_model_finalize(qtts_model* m);
+/* The file side of ModelLoader::load_tts_model (model/loader.rs:267-324) in one call: <model_dir>/config.json,
+ * speech_tokenizer/config.json (when load_tokenizer), every tensor of model.safetensors - or, as in the reference, of the FIRST
+ * model-*.safetensors shard (model/loader.rs:219-235) - and of speech_tokenizer/model.safetensors through read-only mappings
+ * (F32, BF16 and F16 tensors; encoder.* only when load_encoder, as with_encoder does), then qtts_model_finalize.
+ * QTTS_ERR_IO: a file is missing or malformed. */
+int qtts_model_load_dir(qtts_ctx* ctx, const char* model_dir, int dtype, int load_tokenizer, int load_encoder,
+                        qtts_model** out);
 void qtts_model_free(qtts_model* m);
 
 /* Decode sessions.  No counterpart in the reference (one ConditionalGeneration serves one generate call at a time).

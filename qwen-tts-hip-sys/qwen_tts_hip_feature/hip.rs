@@ -152,6 +152,26 @@ impl HipModel {
         Ok(model)
     }
 
+    /// The same from a checkpoint directory, read by the library itself (`qtts_model_load_dir`): config.json,
+    /// speech_tokenizer/config.json and the safetensors files, mapped read-only; `with_encoder` as in `ModelLoader::with_encoder`.
+    pub fn load_dir(dev: &HipDevice, model_dir: &std::path::Path, bf16: bool, load_tokenizer: bool, with_encoder: bool) -> Result<Self, HipError> {
+        let dir = CString::new(model_dir.to_string_lossy().as_bytes()).expect("path holds no NUL");
+        let mut m = ptr::null_mut();
+        check(unsafe {
+            sys::qtts_model_load_dir(
+                dev.ctx,
+                dir.as_ptr(),
+                if bf16 { sys::QTTS_BF16 } else { sys::QTTS_F32 },
+                load_tokenizer as c_int,
+                with_encoder as c_int,
+                &mut m,
+            )
+        })?;
+        let mut model = Self { m, session: false, hidden: 0, vocab: 0, groups: 0, total_upsample: 0, enc_dim: 0 };
+        model.query_info()?;
+        Ok(model)
+    }
+
     fn query_info(&mut self) -> Result<(), HipError> {
         let (mut h, mut v, mut g, mut u, mut e) = (0, 0, 0, 0, 0);
         check(unsafe { sys::qtts_model_info(self.m, &mut h, &mut v, &mut g, &mut u, &mut e) })?;

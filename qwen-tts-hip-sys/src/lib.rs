@@ -10,6 +10,7 @@ pub const QTTS_ERR_HIP: c_int = -2;
 pub const QTTS_ERR_OOM: c_int = -3;
 pub const QTTS_ERR_SHAPE: c_int = -4;
 pub const QTTS_ERR_STATE: c_int = -5;
+pub const QTTS_ERR_IO: c_int = -6;
 
 pub const QTTS_F32: c_int = 0;
 pub const QTTS_BF16: c_int = 1;
@@ -116,6 +117,14 @@ extern "C" {
         rank: c_int,
     ) -> c_int;
     pub fn qtts_model_finalize(m: *mut qtts_model) -> c_int;
+    pub fn qtts_model_load_dir(
+        ctx: *mut qtts_ctx,
+        model_dir: *const c_char,
+        dtype: c_int,
+        load_tokenizer: c_int,
+        load_encoder: c_int,
+        out: *mut *mut qtts_model,
+    ) -> c_int;
     pub fn qtts_model_free(m: *mut qtts_model);
 
     pub fn qtts_session_open(m: *mut qtts_model, out: *mut *mut qtts_session) -> c_int;

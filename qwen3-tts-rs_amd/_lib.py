@@ -48,7 +48,7 @@ class GenDebug(C.Structure):
 
 
 EXPORTS = ["qtts_init", "qtts_shutdown", "qtts_last_error", "qtts_stream", "qtts_model_create", "qtts_model_load_tensor",
-           "qtts_model_load_tensor_device", "qtts_model_finalize", "qtts_model_free", "qtts_generate", "qtts_generate_ex",
+           "qtts_model_load_tensor_device", "qtts_model_finalize", "qtts_model_load_dir", "qtts_model_free", "qtts_generate", "qtts_generate_ex",
            "qtts_last_timing", "qtts_codec_decode", "qtts_mel", "qtts_speaker_embed", "qtts_model_info",
            "qtts_gemm_profile", "qtts_bench_gemm", "qtts_bench_stream", "qtts_encode_audio",
            "qtts_speaker_embed_mel", "qtts_codec_stream_open", "qtts_codec_stream_push", "qtts_codec_stream_close",
@@ -76,6 +76,7 @@ def load():
     lib.qtts_model_load_tensor.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int]
     lib.qtts_model_load_tensor_device.argtypes = lib.qtts_model_load_tensor.argtypes
     lib.qtts_model_finalize.argtypes = [C.c_void_p]
+    lib.qtts_model_load_dir.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     lib.qtts_model_free.argtypes = [C.c_void_p]
     lib.qtts_model_free.restype = None
     lib.qtts_session_open.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]

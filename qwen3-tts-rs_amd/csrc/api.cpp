@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "generate.hpp"
+#include "loader.hpp"
 
 using namespace qtts;
 
@@ -128,6 +129,19 @@ int qtts_model_finalize(qtts_model* m) {
     QTTS_API_BEGIN
     QTTS_CHECK(m, ERR_BAD_ARG, "qtts_model_finalize: null model");
     m->m.finalize();
+    QTTS_API_END
+}
+
+int qtts_model_load_dir(qtts_ctx* ctx, const char* model_dir, int dtype, int load_tokenizer, int load_encoder, qtts_model** out) {
+    QTTS_API_BEGIN
+    QTTS_CHECK(ctx && model_dir && out, ERR_BAD_ARG, "qtts_model_load_dir: null argument");
+    QTTS_CHECK(dtype == F32 || dtype == BF16, ERR_BAD_ARG, "qtts_model_load_dir: dtype must be QTTS_F32 or QTTS_BF16");
+    std::unique_ptr<qtts_model> m(new qtts_model());
+    m->m.ctx = &ctx->c;
+    m->m.dtype = dtype;
+    QTTS_HIP(hipSetDevice(ctx->c.device));
+    load_model_dir(m->m, model_dir, load_tokenizer != 0, load_encoder != 0);
+    *out = m.release();
     QTTS_API_END
 }
 

@@ -17,7 +17,7 @@ struct Error : std::runtime_error {
     Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
 };
 // error classes returned through the C ABI
-constexpr int ERR_BAD_ARG = -1, ERR_HIP = -2, ERR_OOM = -3, ERR_SHAPE = -4, ERR_STATE = -5;
+constexpr int ERR_BAD_ARG = -1, ERR_HIP = -2, ERR_OOM = -3, ERR_SHAPE = -4, ERR_STATE = -5, ERR_IO = -6;
 
 #define QTTS_HIP(expr)                                                                                   \
     do {                                                                                                 \

@@ -1,0 +1,162 @@
+// Model directory -> Model, natively: the file side of ModelLoader::load_tts_model (qwen_tts/src/model/loader.rs:267-324).
+// Reads config.json, speech_tokenizer/config.json and the safetensors files through read-only mappings and hands every tensor
+// to Model::load_tensor under its HF key.  Like the reference, a sharded checkpoint contributes its first shard only
+// (model/loader.rs:219-235), and encoder.* tensors are loaded only on request (LoaderConfig / with_encoder).
+//
+// safetensors layout: u64 little-endian header length n, n bytes of JSON {"key": {"dtype", "shape", "data_offsets": [b, e]}, ..,
+// "__metadata__": {..}}, then the tensor bytes; offsets are relative to the first byte after the header.
+#include <dirent.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+#include "json_min.hpp"
+#include "loader.hpp"
+
+namespace qtts {
+
+namespace {
+
+struct Mapping {  // read-only mapping of a whole file
+    const uint8_t* p = nullptr;
+    size_t n = 0;
+    explicit Mapping(const std::string& path) {
+        const int fd = open(path.c_str(), O_RDONLY);
+        QTTS_CHECK(fd >= 0, ERR_IO, "cannot open " + path);
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size < 8) {
+            close(fd);
+            throw Error(ERR_IO, "not a safetensors file: " + path);
+        }
+        n = (size_t)st.st_size;
+        void* q = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        QTTS_CHECK(q != MAP_FAILED, ERR_IO, "cannot map " + path);
+        p = (const uint8_t*)q;
+    }
+    ~Mapping() {
+        if (p) munmap((void*)p, n);
+    }
+    Mapping(const Mapping&) = delete;
+    Mapping& operator=(const Mapping&) = delete;
+};
+
+bool file_exists(const std::string& path) {
+    struct stat st;
+    return stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+}
+
+std::string read_text(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    QTTS_CHECK(f.good(), ERR_IO, "cannot read " + path);
+    std::ostringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu, bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else {  // subnormal: normalise
+            int e = -1;
+            do {
+                ++e;
+                man <<= 1;
+            } while ((man & 0x400u) == 0);
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13);
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7f800000u | (man << 13);
+    } else {
+        bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    }
+    float f;
+    std::memcpy(&f, &bits, 4);
+    return f;
+}
+
+// every tensor of one safetensors file; returns how many were handed over
+int load_file(Model& m, const std::string& path, bool load_encoder) {
+    Mapping map(path);
+    uint64_t hlen = 0;
+    std::memcpy(&hlen, map.p, 8);
+    QTTS_CHECK(hlen >= 2 && hlen <= map.n - 8, ERR_IO, "bad safetensors header in " + path);
+    const Json header = JsonParser::parse(std::string((const char*)map.p + 8, (size_t)hlen));
+    QTTS_CHECK(header.kind == Json::Obj, ERR_IO, "bad safetensors header in " + path);
+    const uint8_t* data = map.p + 8 + hlen;
+    const size_t data_n = map.n - 8 - (size_t)hlen;
+    int count = 0;
+    std::vector<float> widened;
+    for (const auto& kvp : header.obj) {
+        const std::string& key = kvp.first;
+        if (key == "__metadata__") continue;
+        if (!load_encoder && key.rfind("encoder.", 0) == 0) continue;
+        const Json& t = kvp.second;
+        const std::string dt = t.str_or("dtype", "");
+        const Json& sh = t.at("shape");
+        const Json& off = t.at("data_offsets");
+        QTTS_CHECK(sh.kind == Json::Arr && off.kind == Json::Arr && off.arr.size() == 2, ERR_IO, "bad safetensors entry " + key);
+        std::vector<int64_t> shape;
+        int64_t n = 1;
+        for (const Json& d : sh.arr) {
+            shape.push_back((int64_t)d.num);
+            n *= (int64_t)d.num;
+        }
+        const size_t b = (size_t)off.arr[0].num, e = (size_t)off.arr[1].num;
+        const size_t es = dt == "F32" ? 4 : ((dt == "BF16" || dt == "F16") ? 2 : 0);
+        QTTS_CHECK(es != 0, ERR_IO, "tensor " + key + " has dtype " + dt + " (F32, BF16 and F16 are read)");
+        QTTS_CHECK(b <= e && e <= data_n && e - b == (size_t)n * es, ERR_IO, "tensor " + key + " does not match its data range");
+        if (shape.empty()) shape.push_back(1);  // a scalar is a vector of one
+        if (dt == "F16") {
+            widened.resize((size_t)n);
+            const uint16_t* s = (const uint16_t*)(data + b);
+            for (int64_t i = 0; i < n; ++i) widened[(size_t)i] = f16_to_f32(s[i]);
+            m.load_tensor(key, widened.data(), F32, shape.data(), (int)shape.size(), false);
+        } else {
+            m.load_tensor(key, data + b, dt == "F32" ? F32 : BF16, shape.data(), (int)shape.size(), false);
+        }
+        ++count;
+    }
+    return count;
+}
+
+}  // namespace
+
+void load_model_dir(Model& m, const std::string& dir, bool load_tokenizer, bool load_encoder) {
+    const std::string cfg_path = dir + "/config.json";
+    QTTS_CHECK(file_exists(cfg_path), ERR_IO, "config.json not found in " + dir);
+    const std::string codec_cfg_path = dir + "/speech_tokenizer/config.json";
+    const bool codec = load_tokenizer && file_exists(codec_cfg_path);
+    const std::string cfg = read_text(cfg_path);
+    const std::string codec_cfg = codec ? read_text(codec_cfg_path) : std::string();
+    m.parse_config(cfg, codec ? codec_cfg.c_str() : nullptr);
+    std::string main = dir + "/model.safetensors";
+    if (!file_exists(main)) {
+        std::vector<std::string> shards;
+        if (DIR* d = opendir(dir.c_str())) {
+            while (dirent* ent = readdir(d)) {
+                const std::string f = ent->d_name;
+                if (f.rfind("model-", 0) == 0 && f.size() > 12 && f.compare(f.size() - 12, 12, ".safetensors") == 0) shards.push_back(f);
+            }
+            closedir(d);
+        }
+        QTTS_CHECK(!shards.empty(), ERR_IO, "no model.safetensors in " + dir);
+        std::sort(shards.begin(), shards.end());
+        main = dir + "/" + shards[0];
+    }
+    load_file(m, main, load_encoder);
+    const std::string tok = dir + "/speech_tokenizer/model.safetensors";
+    if (codec && file_exists(tok)) load_file(m, tok, load_encoder);
+    m.finalize();
+}
+
+}  // namespace qtts

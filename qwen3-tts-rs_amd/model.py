@@ -693,6 +693,29 @@ class ModelLoader:
         return m.finalize()
 
 
+    def load_tts_model_native(self, loader: LoaderConfig = LoaderConfig()) -> Model:
+        """The same model through the library's own file reader (qtts_model_load_dir): configs and safetensors files are read
+        and mapped by the C++ side, nothing passes through numpy.  What a Rust caller of the C ABI would use."""
+        m = Model.__new__(Model)
+        m.lib = _lib.load()
+        m.config, m.codec_config = self.config, (self.codec_config if loader.load_tokenizer else None)
+        m.generate_defaults = self.generate_defaults
+        m.dtype = QTTS_BF16 if loader.dtype in ("bf16", "bfloat16") else QTTS_F32
+        m._ctx = C.c_void_p()
+        m._m = C.c_void_p()
+        m._finalized = False
+        m.last_timing = None
+        m.text_processor = None
+        check(m.lib.qtts_init(loader.device, C.byref(m._ctx)))
+        check(m.lib.qtts_model_load_dir(m._ctx, os.fsencode(self.model_dir), m.dtype, 1 if loader.load_tokenizer else 0,
+                                        1 if loader.load_encoder else 0, C.byref(m._m)))
+        m._finalized = True
+        if loader.load_text_tokenizer and os.path.exists(os.path.join(self.model_dir, "tokenizer.json")):
+            from .text import TextProcessor
+            m.text_processor = TextProcessor.from_pretrained(self.model_dir)
+        return m
+
+
 def synthetic_model(shape: str, dtype: str = "bf16", seed: int = 20261111, model_type: str = "custom_voice", codec: bool = True,
                     talker: bool = True, device: int = 0, round_to_bf16: bool = False, encoder: bool = False):
     """Random-init model of a named shape set (see synth.py).  Returns (Model, config, codec_config, template)."""

@@ -89,3 +89,73 @@ def test_model_loader_reads_a_safetensors_directory(tmp_path, bind, golden):
         m.close()
     with pytest.raises(FileNotFoundError):
         ModelLoader.from_local_dir(str(tmp_path / "nowhere"))
+
+
+def _write_model_dir(d, cfg, ccfg, tensors_main, tensors_codec, main_name="model.safetensors"):
+    from safetensors.torch import save_file
+    (d / "speech_tokenizer").mkdir(parents=True)
+    json.dump(cfg, open(d / "config.json", "w"))
+    json.dump(ccfg, open(d / "speech_tokenizer" / "config.json", "w"))
+    json.dump(dict(do_sample=False, subtalker_dosample=False, temperature=1.0, max_new_tokens=16), open(d / "generate_config.json", "w"))
+    save_file(tensors_main, str(d / main_name))
+    save_file(tensors_codec, str(d / "speech_tokenizer" / "model.safetensors"))
+
+
+@pytest.mark.gpu
+def test_native_directory_loader_matches_the_python_one(tmp_path, golden):
+    """qtts_model_load_dir (the C++ file reader a Rust caller would use) on checkpoint-shaped directories: F32 tensors give the
+    golden greedy tokens and the Python loader's waveform; a first-shard file name is found like model.safetensors; BF16- and
+    F16-stored tensors load into a bf16 model exactly as their f32 values would; missing or cut files are I/O errors."""
+    import torch
+    from conftest import SEED
+    from qwen3_tts_rs_amd import LoaderConfig, ModelLoader, QttsError, synth
+    cfg, ccfg, tmpl = synth.shape_set("T0")
+    main = {k: torch.from_numpy(np.ascontiguousarray(a)) for k, a in synth.iter_weights(synth.talker_keys(cfg), SEED)}
+    codec = {k: torch.from_numpy(np.ascontiguousarray(a)) for k, a in synth.iter_weights(synth.codec_keys(ccfg), SEED)}
+    codec["encoder.ignored.weight"] = torch.zeros(4, 4)
+    _write_model_dir(tmp_path / "f32", cfg, ccfg, main, codec, main_name="model-00001-of-00002.safetensors")
+    loader = ModelLoader.from_local_dir(str(tmp_path / "f32"))
+    a = loader.load_tts_model(LoaderConfig(dtype="f32"))
+    b = loader.load_tts_model_native(LoaderConfig(dtype="f32"))
+    try:
+        ra = a.generate_custom_voice_full(golden["text_ids"], "speaker1", "english")
+        rb = b.generate_custom_voice_full(golden["text_ids"], "speaker1", "english")
+        assert np.array_equal(ra.codes, rb.codes) and list(ra.effective_lengths) == list(rb.effective_lengths)
+        assert np.array_equal(ra.codes[0], golden["greedy_codes"][:16])
+        assert np.array_equal(ra.audio[0], rb.audio[0])
+    finally:
+        a.close()
+        b.close()
+    # the same weights stored as BF16 / F16 (values that both formats hold exactly) against F32 storage, loaded into bf16 models
+    exact = lambda t: t.to(torch.bfloat16).to(torch.float16).to(torch.float32) if t.dtype == torch.float32 else t
+    both = lambda t: exact(exact(t))
+    m16 = {k: both(t) for k, t in main.items()}
+    c16 = {k: both(t) for k, t in codec.items()}
+    ok = all(torch.equal(t.to(torch.bfloat16).to(torch.float32), t) and torch.equal(t.to(torch.float16).to(torch.float32), t) for t in m16.values())
+    assert ok, "test setup: values must be exact in both 16-bit formats"
+    _write_model_dir(tmp_path / "s32", cfg, ccfg, m16, c16)
+    _write_model_dir(tmp_path / "sbf", cfg, ccfg, {k: t.to(torch.bfloat16) for k, t in m16.items()}, {k: t.to(torch.bfloat16) for k, t in c16.items()})
+    _write_model_dir(tmp_path / "sf16", cfg, ccfg, {k: t.to(torch.float16) for k, t in m16.items()}, {k: t.to(torch.float16) for k, t in c16.items()})
+    outs = []
+    for name in ("s32", "sbf", "sf16"):
+        m = ModelLoader.from_local_dir(str(tmp_path / name)).load_tts_model_native(LoaderConfig(dtype="bf16"))
+        try:
+            r = m.generate_custom_voice_full(golden["text_ids"], "speaker1", "english")
+            outs.append((r.codes.copy(), r.audio[0].copy()))
+        finally:
+            m.close()
+    for codes, audio in outs[1:]:
+        assert np.array_equal(codes, outs[0][0]) and np.array_equal(audio, outs[0][1])
+    # errors
+    (tmp_path / "empty").mkdir()
+    json.dump(cfg, open(tmp_path / "empty" / "config.json", "w"))
+    with pytest.raises(QttsError) as ei:
+        ModelLoader.from_local_dir(str(tmp_path / "empty")).load_tts_model_native(LoaderConfig(dtype="f32"))
+    assert ei.value.code == -6 and "model.safetensors" in str(ei.value)
+    cut = tmp_path / "cut"
+    _write_model_dir(cut, cfg, ccfg, main, codec)
+    raw = open(cut / "model.safetensors", "rb").read()
+    open(cut / "model.safetensors", "wb").write(raw[: len(raw) // 2])
+    with pytest.raises(QttsError) as ei:
+        ModelLoader.from_local_dir(str(cut)).load_tts_model_native(LoaderConfig(dtype="f32"))
+    assert ei.value.code == -6
