@@ -159,3 +159,45 @@ def test_native_directory_loader_matches_the_python_one(tmp_path, golden):
     with pytest.raises(QttsError) as ei:
         ModelLoader.from_local_dir(str(cut)).load_tts_model_native(LoaderConfig(dtype="f32"))
     assert ei.value.code == -6
+
+
+@pytest.mark.gpu
+def test_compiled_host_program_drives_the_c_abi(tmp_path, golden):
+    """tools/qtts_synth (plain C++ on include/qtts.h: load_dir -> generate -> codec_decode -> WAV) gives the golden greedy tokens
+    and, byte for byte, the WAV files the Python mirror writes for the same batch."""
+    import subprocess
+    import torch
+    from conftest import ROOT, SEED
+    from qwen3_tts_rs_amd import GenerationRequest, LoaderConfig, ModelLoader, SamplingConfig, synth
+    from qwen3_tts_rs_amd.io import write_wav
+    exe = os.path.join(ROOT, "tools", "qtts_synth")
+    assert os.path.exists(exe), "tools/qtts_synth is built by make -C qwen3-tts-rs_amd/csrc"
+    cfg, ccfg, tmpl = synth.shape_set("T0")
+    main = {k: torch.from_numpy(np.ascontiguousarray(a)) for k, a in synth.iter_weights(synth.talker_keys(cfg), SEED)}
+    codec = {k: torch.from_numpy(np.ascontiguousarray(a)) for k, a in synth.iter_weights(synth.codec_keys(ccfg), SEED)}
+    d = tmp_path / "model"
+    _write_model_dir(d, cfg, ccfg, main, codec)
+    texts = [np.asarray(golden["text_ids"]), synth.synthetic_text_ids(tmpl, 9, 1)]
+    with open(tmp_path / "ids.txt", "w") as f:
+        for t in texts:
+            f.write(" ".join(str(int(v)) for v in t) + "\n")
+    r = subprocess.run([exe, str(d), str(tmp_path / "ids.txt"), str(tmp_path / "out.wav"), "--speaker", "speaker1", "--language", "english",
+                        "--dtype", "f32", "--max-new-tokens", "16", "--greedy", "--codes", str(tmp_path / "codes.txt")],
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    blocks = [b for b in open(tmp_path / "codes.txt").read().split("\n\n") if b.strip()]
+    got = [np.array([[int(v) for v in line.split()] for line in b.strip().split("\n")], np.uint32) for b in blocks]
+    m = ModelLoader.from_local_dir(str(d)).load_tts_model_native(LoaderConfig(dtype="f32"))
+    try:
+        out = m.generate([GenerationRequest(text_ids=t, language="english", speaker="speaker1") for t in texts], SamplingConfig.cli_greedy(), 16)
+        wavs = m.decode_output(out)
+    finally:
+        m.close()
+    assert np.array_equal(got[0], golden["greedy_codes"][:len(got[0])])
+    for i in range(2):
+        assert np.array_equal(got[i], out.codes[i][:out.effective_lengths[i]])
+        write_wav(str(tmp_path / f"py.{i}.wav"), wavs[i], 24000)
+        assert open(tmp_path / f"out.{i}.wav", "rb").read() == open(tmp_path / f"py.{i}.wav", "rb").read()
+    # errors surface with the library's message and a non-zero status
+    r = subprocess.run([exe, str(tmp_path / "nowhere"), str(tmp_path / "ids.txt"), str(tmp_path / "x.wav")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "config.json not found" in r.stderr
