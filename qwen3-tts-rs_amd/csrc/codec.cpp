@@ -55,7 +55,7 @@ struct CodecState {
 struct CodecScratch {
     Workspace ws;
     StackW xf;
-    DevBuf kv, toks, tiles, meta, codes, A, Bf, R, Rf, acc, wav;
+    DevBuf kv, toks, tiles, meta, codes, A, Bf, R, Rf, Rf2, acc, wav;
 };
 
 static CodecScratch& codec_scratch(Model& m) {
@@ -218,14 +218,26 @@ struct Geometry {
     size_t act_elems = 0, acc_elems = 0, res_elems = 0;
     size_t lo_elems = 0;  // largest tensor that carries a remainder plane in bf16 runs (the low-rate stages)
     long wav_max = 0;
-    size_t bytes(size_t es) const { return (act_elems + lo_elems) * es * 3 + (acc_elems + res_elems) * 4 + (size_t)U * (size_t)wav_max * 4; }
+    size_t bytes(size_t es) const {
+        return (act_elems + lo_elems) * es * 3 + (acc_elems + res_elems * (size_t)(f32_units ? 2 : 1)) * 4 + (size_t)U * (size_t)wav_max * 4;
+    }
+    bool f32_units = false;  // the fused residual units read the f32 stream (two f32 buffers, written in turn)
 };
 
 constexpr long SLACK_ROWS = CONV_HALO_SLACK + 64;  // readable rows past the last strip: 64-row GEMM tile padding + tap offsets
 constexpr int SPLIT_BLOCKS = 2;  // vocoder blocks whose transposed conv reads an input with a remainder plane (bf16 runs)
 
-Geometry make_geometry(const CodecCfg& c, const CodecState& s, int U, int Tm) {
+// bf16 runs: the fused residual units make their activated input from the f32 stream, so that no activated copy travels between
+// the layers of a vocoder block (a third fewer bytes per row in its byte-bound narrow stages; the values are the same bit for
+// bit).  QTTS_UNIT_F32IN=0: activated copies as before.
+bool unit_f32in(int dtype) {
+    static const int mode = getenv("QTTS_UNIT_F32IN") ? atoi(getenv("QTTS_UNIT_F32IN")) : 1;
+    return dtype == BF16 && mode != 0;
+}
+
+Geometry make_geometry(const CodecCfg& c, const CodecState& s, int U, int Tm, int dtype) {
     Geometry g;
+    g.f32_units = unit_f32in(dtype);
     g.U = U;
     g.nup = (int)c.upsampling_ratios.size();
     g.nb = (int)c.upsample_rates.size();
@@ -334,7 +346,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
     const int U = (int)ps.size();
     int Tm = 0;
     for (auto& p : ps) Tm = std::max(Tm, p.len);
-    const Geometry g = make_geometry(c, s, U, Tm);
+    const Geometry g = make_geometry(c, s, U, Tm, dt);
     const int nup = g.nup, nb = g.nb, nstage = g.nstage;
     const std::vector<long>& S = g.S;
     const std::vector<int>& P = g.P;
@@ -394,6 +406,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
     w.Bf.ensure((g.act_elems + (lo ? g.lo_elems : 0)) * es);
     w.R.ensure((g.act_elems + (lo ? g.lo_elems : 0)) * es);
     w.Rf.ensure(g.res_elems * 4);  // the vocoder's residual stream is kept in f32
+    if (g.f32_units) w.Rf2.ensure(g.res_elems * 4);
     w.acc.ensure(g.acc_elems * 4);
     w.wav.ensure((size_t)U * (size_t)g.wav_max * 4);
 
@@ -570,18 +583,59 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         const int Pn = P[(size_t)so];
         const int CPo = blk.ct.CoutP;
         gemm(blk.ct, xin, Min, CP, b < SPLIT_BLOCKS ? lo : 0);
+        // the block's units read the f32 stream where the fused kernel covers the block's width
+        bool f32in = g.f32_units;
+        for (int u = 0; u < 3; ++u) f32in = f32in && conv_unit_supported(dt, CPo, blk.u[u].c1.taps, blk.u[u].c1.dil);
         zero_pad_rows(w.A.p, S[(size_t)so], Pn, CPo);
         {
             ConvEpi e{};
             e.M = Min; e.N = blk.ct.N; e.r = blk.ct.r; e.Cout = CPo; e.bias = blk.ct.bias.as<float>();
             e.lens = d_lenm1(si); e.S_in = S[(size_t)si]; e.S_out = S[(size_t)so]; e.P_out = Pn; e.ld_out = CPo;
             e.out_f32 = w.Rf.as<float>(); e.out2 = w.A.p; e.alpha_exp = blk.u[0].a1.a.as<float>(); e.beta_den = blk.u[0].a1.den.as<float>();
+            if (f32in) e.out2 = nullptr;  // the first unit activates its own input from Rf
             epilogue(e);
         }
         // Residual units.  Where the fused kernel covers the block's width, each unit is one launch that reads the activated
         // tensor from one buffer and writes the next one to the other (a block of rows reads its neighbours' rows as halo, so
         // the unit cannot work in place); otherwise conv1 and conv2 are two launches through Bf.
-        bool fuse = true;
+        if (f32in) {
+            // leading rows of every strip are the causal padding of the f32 streams the units read (SnakeBeta of 0 is 0)
+            QTTS_HIP(hipMemset2DAsync(w.Rf.p, (size_t)S[(size_t)so] * CPo * 4, 0, (size_t)Pn * CPo * 4, (size_t)U, st));
+            QTTS_HIP(hipMemset2DAsync(w.Rf2.p, (size_t)S[(size_t)so] * CPo * 4, 0, (size_t)Pn * CPo * 4, (size_t)U, st));
+            float* rin = w.Rf.as<float>();
+            float* rout = w.Rf2.as<float>();
+            for (int u = 0; u < 3; ++u) {
+                const CodecState::Unit& un = blk.u[u];
+                ConvEpi e{};
+                e.M = Mout; e.N = CPo; e.r = 1; e.Cout = CPo; e.bias = un.c2.bias.as<float>();
+                e.resid_f32 = rin; e.lens = d_len(so); e.S_in = S[(size_t)so]; e.S_out = S[(size_t)so]; e.P_out = Pn; e.ld_out = CPo;
+                if (u < 2) {
+                    e.out_f32 = rout;  // the next unit reads (and activates) this stream
+                } else {           // after the last unit only the activated copy is read again
+                    const Snake& nx = b + 1 < nb ? s.blocks[(size_t)b + 1].s0 : s.sfinal;
+                    e.alpha_exp = nx.a.as<float>(); e.beta_den = nx.den.as<float>();
+                    e.out2 = w.A.p;
+                    e.out2_lo = b + 1 < SPLIT_BLOCKS ? lo : 0;
+                }
+                Prof pr{};
+                if (profiling) {
+                    pr = Prof{nullptr, nullptr, Mout, CPo, un.c1.K + un.c2.K, un.c1.taps + 1, un.c1.dil};
+                    QTTS_HIP(hipEventCreate(&pr.a));
+                    QTTS_HIP(hipEventCreate(&pr.b));
+                    QTTS_HIP(hipEventRecord(pr.a, st));
+                }
+                const bool ok = launch_conv_unit(st, dt, un.c1.wm(), un.c2.wm(), nullptr, CPo, un.c1.taps, un.c1.dil, un.c1.bias.as<float>(),
+                                                 un.a2.a.as<float>(), un.a2.den.as<float>(), e, rin + (size_t)(Pn - 6 * un.c1.dil) * CPo,
+                                                 un.a1.a.as<float>(), un.a1.den.as<float>());
+                QTTS_CHECK(ok, ERR_STATE, "codec decode: fused residual unit refused a shape it reported as supported");
+                if (profiling) {
+                    QTTS_HIP(hipEventRecord(pr.b, st));
+                    prof.push_back(pr);
+                }
+                std::swap(rin, rout);
+            }
+        }
+        bool fuse = !f32in;
         for (int u = 0; u < 3; ++u) fuse = fuse && conv_unit_supported(dt, CPo, blk.u[u].c1.taps, blk.u[u].c1.dil);
         if (fuse) {
             zero_pad_rows(w.Bf.p, S[(size_t)so], Pn, CPo);
@@ -615,7 +669,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
             }
             std::swap(w.A, w.Bf);  // three units: the block's result sits in the other buffer; A names it again
         }
-        for (int u = 0; u < 3 && !fuse; ++u) {
+        for (int u = 0; u < 3 && !fuse && !f32in; ++u) {
             const CodecState::Unit& un = blk.u[u];
             // conv1 (k = 7, dilated): A -> snake(act2) in Bf
             gemm(un.c1, (const char*)w.A.p + (size_t)(Pn - 6 * un.c1.dil) * CPo * es, Mout, CPo);
@@ -733,13 +787,13 @@ void run_codec_decode(Model& m, const uint32_t* codes, const int* lens, int B, i
     w.codes.ensure((size_t)B * T_max * s.Q * 4);
     copy_sync(w.codes.p, codes, (size_t)B * T_max * s.Q * 4, hipMemcpyHostToDevice, m.ctx->stream);
     // ---- groups bounded by a scratch budget
-    static const size_t budget = (size_t)(getenv("QTTS_CODEC_SCRATCH_MB") ? std::max(64, atoi(getenv("QTTS_CODEC_SCRATCH_MB"))) : 32768) << 20;
+    static const size_t budget = (size_t)(getenv("QTTS_CODEC_SCRATCH_MB") ? std::max(64, atoi(getenv("QTTS_CODEC_SCRATCH_MB"))) : 49152) << 20;
     Decoder dec(m);
     size_t i = 0;
     while (i < pieces.size()) {
         const int Tm = pieces[i].len;  // sorted: the first piece of a group is its longest
         size_t n = 1;
-        while (i + n < pieces.size() && n < 4096 && make_geometry(c, s, (int)n + 1, Tm).bytes(dec.es) <= budget) ++n;
+        while (i + n < pieces.size() && n < 4096 && make_geometry(c, s, (int)n + 1, Tm, m.dtype).bytes(dec.es) <= budget) ++n;
         std::vector<Piece> grp(pieces.begin() + (long)i, pieces.begin() + (long)(i + n));
         dec.run_group(w.codes.as<uint32_t>(), T_max, grp, wav_out, wav_stride);
         i += n;
@@ -819,7 +873,7 @@ void codec_stream_push(CodecStream& sc, const uint32_t* codes, int n, float* wav
     const long out = C > 0 ? (long)n * up : L;
     QTTS_CHECK(out >= 1, ERR_SHAPE, "codec stream: the first push is too short to decide any sample");
     QTTS_CHECK(out <= wav_stride, ERR_SHAPE, "codec stream: wav_stride too small");
-    QTTS_CHECK(make_geometry(c, s, B, T).bytes(dtype_size(m.dtype)) <= ((size_t)96 << 30), ERR_OOM,
+    QTTS_CHECK(make_geometry(c, s, B, T, m.dtype).bytes(dtype_size(m.dtype)) <= ((size_t)96 << 30), ERR_OOM,
                "codec stream: batch x chunk needs more than 96 GB of scratch; push fewer frames at a time");
     // context codes in front of the new ones
     std::vector<uint32_t> all((size_t)B * T * Q);

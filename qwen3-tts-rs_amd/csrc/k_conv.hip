@@ -68,6 +68,44 @@ __device__ __forceinline__ void tile_load_dma(uint4* tile, const T* src, int C, 
     }
 }
 
+// The same tile from the f32 stream the previous layer left: every 16-byte slot is eight channels read as f32, put through
+// SnakeBeta (alpha / den of the consuming conv's input activation, as snake_prep leaves them in sn[0 .. C) / sn[C .. 2C) in LDS)
+// and rounded to bf16 - bit for bit the activated copy a producer would have stored, without its round trip through memory.
+// Slots are taken four at a time so that eight loads per thread are in flight.
+__device__ __forceinline__ void tile_load_snake(uint4* tile, const float* src, int C, int vpr, int total, const float* sn) {
+    constexpr int U = 4;
+    for (int L0 = threadIdx.x; L0 < total; L0 += 256 * U) {
+        float4 a[U], b[U];
+        int col[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int L = L0 + 256 * k;
+            const int Lc = L < total ? L : L0;
+            const int row = Lc / vpr, pcol = Lc - row * vpr;
+            col[k] = (pcol ^ (row & 7)) * 8;
+            const float* p = src + (long)row * C + col[k];
+            a[k] = *reinterpret_cast<const float4*>(p);
+            b[k] = *reinterpret_cast<const float4*>(p + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int L = L0 + 256 * k;
+            if (L >= total) continue;
+            const float x[8] = {a[k].x, a[k].y, a[k].z, a[k].w, b[k].x, b[k].y, b[k].z, b[k].w};
+            float al[8], dn[8];
+            *reinterpret_cast<float4*>(al) = *reinterpret_cast<const float4*>(sn + col[k]);
+            *reinterpret_cast<float4*>(al + 4) = *reinterpret_cast<const float4*>(sn + col[k] + 4);
+            *reinterpret_cast<float4*>(dn) = *reinterpret_cast<const float4*>(sn + C + col[k]);
+            *reinterpret_cast<float4*>(dn + 4) = *reinterpret_cast<const float4*>(sn + C + col[k] + 4);
+            u16 h[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) h[q] = f32_to_bf16_bits(snake_apply<bf16_t>(x[q], al[q], dn[q]));
+            tile[L] = make_uint4((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16),
+                                 (unsigned)h[4] | ((unsigned)h[5] << 16), (unsigned)h[6] | ((unsigned)h[7] << 16));
+        }
+    }
+}
+
 // Block -> tile map of the conv kernels.  The grid is one-dimensional and a multiple of 8 long; blocks are handed to the eight
 // XCDs round-robin, so block b works on tile p = (b % 8) * (grid / 8) + b / 8: consecutive tiles - the column blocks of one row
 // block, then the next row block - run on ONE XCD and find the input rows they share (the same tile for every column block, the
@@ -433,10 +471,12 @@ bool try_tile(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, int
 // column tiles (of 64) per epilogue pass of the fused unit: two where the f32 staging tile then still fits beside the others
 constexpr int unit_pt(int MT, int NT) { return (NT % 2 == 0 && MT <= 4) ? 2 : 1; }
 
-template <typename T, int MT, int NT>
+// F32IN (bf16 only): X is null and the input tile is made from the f32 stream Xf with the input activation (alpha1, den1).
+template <typename T, int MT, int NT, bool F32IN = false>
 __global__ __launch_bounds__(256, (NT == 3 && sizeof(T) == 2) ? 2 : 1) void conv_unit_kernel(const T* __restrict__ W1, const T* __restrict__ W2, int wpk, const T* __restrict__ X, int taps,
                                                         int dil, const float* __restrict__ bias1, const float* __restrict__ alpha2,
-                                                        const float* __restrict__ den2, int xcd, ConvEpi e) {
+                                                        const float* __restrict__ den2, int xcd, ConvEpi e, const float* __restrict__ Xf,
+                                                        const float* __restrict__ alpha1, const float* __restrict__ den1) {
     using F = CFrag<T>;
     extern __shared__ uint4 tile[];
     constexpr int RT = 16 * MT;
@@ -454,7 +494,7 @@ __global__ __launch_bounds__(256, (NT == 3 && sizeof(T) == 2) ? 2 : 1) void conv
     const int K = taps * C, nC = taps * cpt;
     const int tile_slots = (max(rows_t * vpr * 16, RT * (64 * unit_pt(MT, NT) + 4) * 4) + 1023) / 1024 * 64;
     uint4* htile = tile + tile_slots;
-    tile_load_dma<T>(tile, X + m0 * C, C, vpr, rows_t * vpr);
+    if constexpr (!F32IN) tile_load_dma<T>(tile, X + m0 * C, C, vpr, rows_t * vpr);
     constexpr int PT = unit_pt(MT, NT);
     constexpr int CP = 64 * PT, OP = CP + 4, GPR = CP / 4;
     constexpr int EU = (RT / (256 / GPR) >= 8 ? 8 : RT / (256 / GPR));
@@ -472,6 +512,17 @@ __global__ __launch_bounds__(256, (NT == 3 && sizeof(T) == 2) ? 2 : 1) void conv
         }
         row_u[threadIdx.x] = uu;
         row_tp[threadIdx.x] = tt;
+    }
+    if constexpr (F32IN) {
+        __shared__ float sn1[2 * C];
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float al = alpha1[c], dn = den1[c];
+            snake_prep<bf16_t>(al, dn);
+            sn1[c] = al;
+            sn1[C + c] = dn;
+        }
+        __syncthreads();
+        tile_load_snake(tile, Xf + m0 * C, C, vpr, rows_t * vpr, sn1);
     }
     f32x4_t acc[MT][NT];
 #pragma unroll
@@ -590,9 +641,15 @@ __global__ __launch_bounds__(256, (NT == 3 && sizeof(T) == 2) ? 2 : 1) void conv
 
 bool conv_unit_supported_fwd(int dtype, int C, int taps, int dil);
 
+struct UnitIn {  // f32 input stream of a fused unit instead of an activated copy (bf16 runs): stream, input activation parameters
+    const float* Xf = nullptr;
+    const float* alpha1 = nullptr;
+    const float* den1 = nullptr;
+};
+
 template <typename T, int NT, int MT = 4>
 bool launch_unit(hipStream_t st, const T* W1, const T* W2, int wpk, const T* X, int taps, int dil, const float* bias1, const float* alpha2,
-                 const float* den2, const ConvEpi& e) {
+                 const float* den2, const ConvEpi& e, const UnitIn& in = UnitIn()) {
     constexpr int RT = 16 * MT, C = 64 * NT, PT = unit_pt(MT, NT);
     const size_t tile_b = (std::max((size_t)(RT + (taps - 1) * dil) * C * sizeof(T), (size_t)RT * (64 * PT + 4) * 4) + 1023) / 1024 * 1024;
     const size_t lds = tile_b + (size_t)RT * C * sizeof(T);
@@ -602,28 +659,39 @@ bool launch_unit(hipStream_t st, const T* W1, const T* W2, int wpk, const T* X, 
     const int xcd = conv_xcd_order();
     unsigned grid = 0;
     if (!conv_grid(gx, xcd, grid)) return false;
+    if constexpr (sizeof(T) == 2 && MT == 4) {
+        if (in.Xf) {
+            auto* fnf = conv_unit_kernel<T, MT, NT, true>;
+            QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fnf), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_CEILING));
+            hipLaunchKernelGGL(fnf, dim3(grid), dim3(256), lds, st, W1, W2, wpk, (const T*)nullptr, taps, dil, bias1, alpha2, den2, xcd, e, in.Xf, in.alpha1,
+                               in.den1);
+            return true;
+        }
+    }
+    if (in.Xf) return false;
     auto* fn = conv_unit_kernel<T, MT, NT>;
     QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_CEILING));
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, xcd, e);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, xcd, e, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr);
     return true;
 }
 
 template <typename T>
 bool try_unit(hipStream_t st, const T* W1, const T* W2, int wpk, const T* X, int C, int taps, int dil, const float* bias1, const float* alpha2,
-              const float* den2, const ConvEpi& e) {
+              const float* den2, const ConvEpi& e, const UnitIn& in = UnitIn()) {
     if (e.N != C || e.r != 1 || !conv_unit_supported_fwd(sizeof(T) == 2 ? BF16 : F32, C, taps, dil)) return false;
-    if (C == 64) return launch_unit<T, 1>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e);
+    if (C == 64) return launch_unit<T, 1>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e, in);
     if (C == 128) {
         // QTTS_UNIT_ROWS=128: 128-row tiles at 128 channels (every weight fragment feeds eight row tiles instead of four)
         static const int rows = getenv("QTTS_UNIT_ROWS") ? atoi(getenv("QTTS_UNIT_ROWS")) : 64;
         if constexpr (sizeof(T) == 2) {
-            if (rows == 128 && e.M >= 128L * 512 && launch_unit<T, 2, 8>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e)) return true;
+            if (!in.Xf && rows == 128 && e.M >= 128L * 512 && launch_unit<T, 2, 8>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e)) return true;
         }
-        return launch_unit<T, 2>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e);
+        return launch_unit<T, 2>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e, in);
     }
-    if (C == 192) return launch_unit<T, 3>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e);
+    if (C == 192) return launch_unit<T, 3>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e, in);
     if constexpr (sizeof(T) == 2) {
-        if (C == 256) return launch_unit<T, 4>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e);
+        if (C == 256) return launch_unit<T, 4>(st, W1, W2, wpk, X, taps, dil, bias1, alpha2, den2, e, in);
     }
     return false;
 }
@@ -714,12 +782,15 @@ bool conv_unit_supported_fwd(int dtype, int C, int taps, int dil) { return conv_
 // epilogue e (bias, f32 residual, outputs).  X as for launch_conv_halo.  False = shape not covered (the caller launches the two
 // convs one after the other).
 bool launch_conv_unit(hipStream_t st, int dtype, WMat W1m, WMat W2m, const void* X, int C, int taps, int dil, const float* bias1,
-                      const float* alpha2, const float* den2, const ConvEpi& e) {
+                      const float* alpha2, const float* den2, const ConvEpi& e, const float* Xf, const float* alpha1, const float* den1) {
     const void *W1 = W1m.p, *W2 = W2m.p;
     QTTS_CHECK(W1m.packed == W2m.packed, ERR_BAD_ARG, "conv_unit: the two weight matrices must share a layout");
     const int wpk = W1m.packed ? 1 : 0;
-    QTTS_CHECK(W1 && W2 && X && bias1 && alpha2 && den2 && e.lens && e.M >= 1 && e.S_in >= 1, ERR_BAD_ARG, "conv_unit: null argument");
-    if (dtype == BF16) return try_unit<bf16_t>(st, (const bf16_t*)W1, (const bf16_t*)W2, wpk, (const bf16_t*)X, C, taps, dil, bias1, alpha2, den2, e);
+    QTTS_CHECK(W1 && W2 && (X || Xf) && bias1 && alpha2 && den2 && e.lens && e.M >= 1 && e.S_in >= 1, ERR_BAD_ARG, "conv_unit: null argument");
+    QTTS_CHECK(!Xf || (dtype == BF16 && alpha1 && den1 && !X), ERR_BAD_ARG, "conv_unit: an f32 input stream needs a bf16 run and the input activation's parameters");
+    UnitIn in;
+    in.Xf = Xf; in.alpha1 = alpha1; in.den1 = den1;
+    if (dtype == BF16) return try_unit<bf16_t>(st, (const bf16_t*)W1, (const bf16_t*)W2, wpk, (const bf16_t*)X, C, taps, dil, bias1, alpha2, den2, e, in);
     return try_unit<float>(st, (const float*)W1, (const float*)W2, wpk, (const float*)X, C, taps, dil, bias1, alpha2, den2, e);
 }
 

@@ -277,8 +277,11 @@ constexpr long CONV_HALO_SLACK = 448;
 bool launch_conv_halo(hipStream_t st, int dtype, WMat W, const void* X, int K, int ldx, int taps, long tap_stride, const ConvEpi& e,
                       long x_lo = 0);
 bool conv_unit_supported(int dtype, int C, int taps, int dil);
+// Xf (bf16 runs, X null): the unit makes its activated input tile itself from the f32 stream Xf (same addressing as X) with the
+// input activation (alpha1, den1) - no activated copy is read, and the producer need not write one.
 bool launch_conv_unit(hipStream_t st, int dtype, WMat W1, WMat W2, const void* X, int C, int taps, int dil, const float* bias1,
-                      const float* alpha2, const float* den2, const ConvEpi& e);
+                      const float* alpha2, const float* den2, const ConvEpi& e, const float* Xf = nullptr, const float* alpha1 = nullptr,
+                      const float* den1 = nullptr);
 void launch_rvq_gather(hipStream_t st, int dtype, const float* table, const unsigned* codes, const int* rows, const int* starts,
                        const int* lens, int U, int Tc, int Q, int csize, int Dc, int T_max, long S, int P, void* out, int ld, long out_lo = 0);
 void launch_dwconv_ln(hipStream_t st, int dtype, const void* x, const float* w, const float* b, const float* ln_w, const float* ln_b,

@@ -75,3 +75,31 @@ def test_tabulated_pass_starts_change_nothing():
         assert r.returncode == 0 and "codes " in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
         digests.append(r.stdout.split("codes ")[1].split()[0])
     assert digests[0] == digests[1]
+
+
+UNIT_SCRIPT = r"""
+import sys, os, hashlib
+import numpy as np
+sys.path.insert(0, ROOT)
+from qwen3_tts_rs_amd import synthetic_model
+m, cfg, ccfg, tmpl = synthetic_model("M0", dtype="bf16", codec=True, talker=False)
+q = ccfg["decoder_config"]["num_quantizers"]
+codes = np.random.default_rng(11).integers(0, ccfg["decoder_config"]["codebook_size"], (3, 40, q)).astype(np.uint32)
+h = hashlib.sha256()
+for w in m.decode_codes(codes, lens=[40, 33, 17]):
+    h.update(np.ascontiguousarray(w).tobytes())
+m.close()
+print("wav", h.hexdigest())
+"""
+
+
+def test_units_reading_the_f32_stream_change_nothing():
+    """bf16 vocoder: a fused residual unit that activates the f32 stream itself computes, for every element, the same function of
+    the same f32 value as the producer that used to store the activated copy - the waveforms are equal bit for bit."""
+    digests = []
+    for env in ({}, {"QTTS_UNIT_F32IN": "0"}):
+        e = dict(os.environ, **env)
+        r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + UNIT_SCRIPT], env=e, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0 and "wav " in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+        digests.append(r.stdout.split("wav ")[1].split()[0])
+    assert digests[0] == digests[1]
