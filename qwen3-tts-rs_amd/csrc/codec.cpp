@@ -228,8 +228,8 @@ constexpr long SLACK_ROWS = CONV_HALO_SLACK + 64;  // readable rows past the las
 constexpr int SPLIT_BLOCKS = 2;  // vocoder blocks whose transposed conv reads an input with a remainder plane (bf16 runs)
 
 // bf16 runs: the fused residual units make their activated input from the f32 stream, so that no activated copy travels between
-// the layers of a vocoder block (a third fewer bytes per row in its byte-bound narrow stages; the values are the same bit for
-// bit).  QTTS_UNIT_F32IN=0: activated copies as before.
+// the layers of a vocoder block (a quarter fewer bytes written per row in its narrow stages, paid for with a second read of the f32
+// rows: measured 3.5 % of a decode; the values are the same bit for bit).  QTTS_UNIT_F32IN=0: activated copies as before.
 bool unit_f32in(int dtype) {
     static const int mode = getenv("QTTS_UNIT_F32IN") ? atoi(getenv("QTTS_UNIT_F32IN")) : 1;
     return dtype == BF16 && mode != 0;
