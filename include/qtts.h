@@ -61,7 +61,7 @@ int qtts_model_finalize(qtts_model* m);
 /* The file side of ModelLoader::load_tts_model (model/loader.rs:267-324) in one call: <model_dir>/config.json,
  * speech_tokenizer/config.json (when load_tokenizer), every tensor of model.safetensors - or, as in the reference, of the FIRST
  * model-*.safetensors shard (model/loader.rs:219-235) - and of speech_tokenizer/model.safetensors through read-only mappings
- * (F32, BF16 and F16 tensors; encoder.* only when load_encoder, as with_encoder does), then qtts_model_finalize.
+ * (F32, BF16 and F16 tensors, others are skipped; encoder.* only when load_encoder, as with_encoder does), then qtts_model_finalize.
  * QTTS_ERR_IO: a file is missing or malformed. */
 int qtts_model_load_dir(qtts_ctx* ctx, const char* model_dir, int dtype, int load_tokenizer, int load_encoder,
                         qtts_model** out);

@@ -113,7 +113,7 @@ int load_file(Model& m, const std::string& path, bool load_encoder) {
         }
         const size_t b = (size_t)off.arr[0].num, e = (size_t)off.arr[1].num;
         const size_t es = dt == "F32" ? 4 : ((dt == "BF16" || dt == "F16") ? 2 : 0);
-        QTTS_CHECK(es != 0, ERR_IO, "tensor " + key + " has dtype " + dt + " (F32, BF16 and F16 are read)");
+        if (es == 0) continue;  // integer / bool bookkeeping tensors: nothing on the path reads one
         QTTS_CHECK(b <= e && e <= data_n && e - b == (size_t)n * es, ERR_IO, "tensor " + key + " does not match its data range");
         if (shape.empty()) shape.push_back(1);  // a scalar is a vector of one
         if (dt == "F16") {
