@@ -191,3 +191,17 @@ def test_rust_sys_crate_declares_the_whole_header():
     for fn in ("qtts_model_create", "qtts_model_load_tensor", "qtts_model_finalize", "qtts_generate", "qtts_codec_decode", "qtts_encode_audio",
                "qtts_mel", "qtts_speaker_embed", "qtts_speaker_embed_mel", "qtts_session_open", "qtts_codec_stream_push"):
         assert "sys::" + fn in feat, fn
+
+
+def test_host_example_compiles_against_the_header_alone(tmp_path):
+    """tools/qtts_synth.cpp is host code on include/qtts.h and nothing else: it compiles with plain g++ (no HIP headers), and the
+    header itself is valid C."""
+    import subprocess
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tools", "qtts_synth.cpp")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    probe = tmp_path / "probe.c"
+    probe.write_text('#include "qtts.h"\nint main(void) { return QTTS_ERR_IO == -6 ? 0 : 1; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(probe)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
