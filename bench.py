@@ -225,7 +225,10 @@ def main():
         t_s = time.perf_counter()
         first_ms = []
 
+        cb_ms = []
+
         def on_first(codes):
+            t_cb = time.perf_counter()
             # streaming decode session: the samples this push returns (1920 n - 555) are exactly those of the whole decode
             # a row that already produced EOS (a cb0 outside the codebook) has no audio from that frame on: feed silence codes
             done = np.maximum.accumulate(codes[:, :, 0] >= csize, axis=1)
@@ -233,6 +236,7 @@ def main():
             with mod.open_codec_stream(codes.shape[0], codes.shape[1]) as cs:
                 cs.push(codes)
             first_ms.append((time.perf_counter() - t_s) * 1e3)
+            cb_ms.append((time.perf_counter() - t_cb) * 1e3)
 
         stream_first = not args.no_codec and 2 < args.first_frames < args.frames
         out = mod.generate(reqs, sampling, args.frames, use_graph=not args.no_graph, first_frames=args.first_frames if stream_first else 0,
@@ -243,7 +247,7 @@ def main():
             t_d = time.perf_counter()
             print(f"step: generate wall {(t_g - t_s) * 1e3:.1f} ms (device prefill {mod.last_timing['prefill_ms']:.1f} + frames "
                   f"{mod.last_timing['frames_ms']:.1f}), first-chunk callback at {first_ms[0] if first_ms else 0:.1f} ms, "
-                  f"decode wall {(t_d - t_g) * 1e3:.1f} ms (device {0.0 if args.no_codec else mod.codec_device_ms():.1f})", file=sys.stderr)
+                  f"(the callback took {cb_ms[0] if cb_ms else 0:.1f} ms), decode wall {(t_d - t_g) * 1e3:.1f} ms (device {0.0 if args.no_codec else mod.codec_device_ms():.1f})", file=sys.stderr)
         if record:
             with lock:
                 stats["prefill_ms"] += mod.last_timing["prefill_ms"]
