@@ -492,30 +492,34 @@ __global__ __launch_bounds__(512) void gemm_stream_kernel(const bf16_t* __restri
 constexpr int KS_WAVES = 8;   // waves of a k_split block
 constexpr int KS_GROUP = 6;   // most chunks a wave requests at once (X units in LDS, weight fragments in registers); half with a remainder plane
 
-template <bool LO>
+// MT: 16-row token tiles a block owns (every weight fragment is multiplied with MT X fragments: the X tile of a tile row is read
+// by N / 16 column blocks either way, the weights by rows / (16 MT) row slices)
+template <bool LO, int MT = 1>
 __global__ __launch_bounds__(64 * KS_WAVES) void gemm_k_split_kernel(const bf16_t* __restrict__ W, const bf16_t* __restrict__ X, int N, int K,
                                                                      int ldx, long x_lo, int wpk, int gcap, FusedEpi e) {
     constexpr int NW = KS_WAVES, PL = LO ? 2 : 1, G = KS_GROUP / PL;
     QTTS_TS(0);
-    extern __shared__ uint4 ksm[];  // red[NW][64] partial tiles, then every wave's own X units [NW][PL][gcap][128]
+    extern __shared__ uint4 ksm[];  // red[NW][MT][64] partial tiles, then every wave's own X units [NW][PL][gcap][MT][128]
     f32x4_t* red = reinterpret_cast<f32x4_t*>(ksm);
-    uint4* xw = ksm + NW * 64 + (size_t)(threadIdx.x >> 6) * PL * gcap * 128;
+    uint4* xw = ksm + NW * MT * 64 + (size_t)(threadIdx.x >> 6) * PL * gcap * MT * 128;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int tile = blockIdx.x;
     const int n0 = tile * 16;
-    const int row0 = blockIdx.y * 16;
+    const int row0 = blockIdx.y * 16 * MT;
     const int nC = K / CHUNK;
     const int ca = wave * nC / NW, cb = (wave + 1) * nC / NW;
     const WTileB wt(W, n0, K, lane, wpk);
     const bool shared_w = gridDim.y > 1;
     const int s0 = unit_slot(r, g, 0), s1 = unit_slot(r, g, 1);
-    f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    // the first wave finishes the tile; what its epilogue reads (bias, residual, norm weight) is requested now, so that the
+    f32x4_t acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // wave i < MT finishes row tile i; what its epilogue reads (bias, residual, norm weight) is requested now, so that the
     // memory round trip runs beside the K loop instead of after it
-    const int em = row0 + (lane & 15), en = n0 + 4 * (lane >> 4);
+    const int em = row0 + 16 * (wave < MT ? wave : 0) + (lane & 15), en = n0 + 4 * (lane >> 4);
     float4 pre_b = make_float4(0.f, 0.f, 0.f, 0.f), pre_r = pre_b, pre_w = pre_b;
-    if (wave == 0) {
+    if (wave < MT) {
         if (e.bias) pre_b = *reinterpret_cast<const float4*>(e.bias + en);
         if (e.resid) pre_r = *reinterpret_cast<const float4*>(e.resid + (size_t)em * N + en);
         pre_w = *reinterpret_cast<const float4*>(e.nw + en);
@@ -527,10 +531,12 @@ __global__ __launch_bounds__(64 * KS_WAVES) void gemm_k_split_kernel(const bf16_
         for (int u = 0; u < G; ++u) {
             if (u < gcap && c0 + u < cb) {
 #pragma unroll
-                for (int pl = 0; pl < PL; ++pl) {
-                    dma_half(X + (pl ? x_lo : 0), row0, ldx, (long)(c0 + u) * CHUNK, 0, xw + (pl * gcap + u) * 128, lane);
-                    dma_half(X + (pl ? x_lo : 0), row0, ldx, (long)(c0 + u) * CHUNK, 1, xw + (pl * gcap + u) * 128, lane);
-                }
+                for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        dma_half(X + (pl ? x_lo : 0), row0 + 16 * i, ldx, (long)(c0 + u) * CHUNK, 0, xw + ((pl * gcap + u) * MT + i) * 128, lane);
+                        dma_half(X + (pl ? x_lo : 0), row0 + 16 * i, ldx, (long)(c0 + u) * CHUNK, 1, xw + ((pl * gcap + u) * MT + i) * 128, lane);
+                    }
             }
         }
         BFrag a[G];
@@ -546,20 +552,23 @@ __global__ __launch_bounds__(64 * KS_WAVES) void gemm_k_split_kernel(const bf16_
         for (int u = 0; u < G; ++u) {
             if (u < gcap && c0 + u < cb) {
 #pragma unroll
-                for (int pl = 0; pl < PL; ++pl) acc = mma(a[u], unit_frag(xw + (pl * gcap + u) * 128, s0, s1), acc);
+                for (int pl = 0; pl < PL; ++pl)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) acc[i] = mma(a[u], unit_frag(xw + ((pl * gcap + u) * MT + i) * 128, s0, s1), acc[i]);
             }
         }
     }
     QTTS_TS(1);
-    red[wave * 64 + lane] = acc;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) red[(wave * MT + i) * 64 + lane] = acc[i];
     __syncthreads();
     QTTS_TS(2);
-    // lane l of the first wave: row l & 15, columns n0 + 4 (l >> 4) .. + 3; partial tiles are added in wave order
-    if (wave == 0) {
+    // lane l of wave i < MT: row 16 i + (l & 15), columns n0 + 4 (l >> 4) .. + 3; partial tiles are added in wave order
+    if (wave < MT) {
         const int l = lane;
-        f32x4_t v = red[l];
+        f32x4_t v = red[wave * 64 + l];
 #pragma unroll
-        for (int w = 1; w < NW; ++w) v += red[w * 64 + l];
+        for (int w = 1; w < NW; ++w) v += red[(w * MT + wave) * 64 + l];
         const int m = em, n = en;
         float x[4] = {v[0], v[1], v[2], v[3]};
         if (e.bias) {
@@ -746,18 +755,28 @@ void launch_gemm_k_split(hipStream_t st, WMat Wm, const void* X, int ldx, long x
     const bf16_t* w = (const bf16_t*)Wm.p;
     const bf16_t* x = (const bf16_t*)X;
     const int wpk = Wm.packed ? 1 : 0;
-    dim3 grid(N / 16, rows / 16);
     const int planes = x_lo ? 2 : 1;
     const int per_wave = (K / CHUNK + KS_WAVES - 1) / KS_WAVES;          // chunks of the longest wave slice
     // X chunks a wave requests at once: six alone on the GPU, three with several decode streams in flight (56 instead of 104 KB of
     // LDS per block: blocks of two streams share a CU)
     static const int group_env = getenv("QTTS_KS_GROUP") ? atoi(getenv("QTTS_KS_GROUP")) : 0;
+    // token rows per block: 16 alone on the GPU, 32 with several decode streams in flight (every weight fragment meets two X
+    // fragments: half the weight reads through the L1s and half the blocks; 4.82 against 4.69 ms per frame alone, 1953 against
+    // 1924 audio-s/s without the codec with three sessions).  QTTS_KS_ROWS=16 / 32 forces either.
+    static const int rows_env = getenv("QTTS_KS_ROWS") ? atoi(getenv("QTTS_KS_ROWS")) : 0;
+    const int want = rows_env == 16 || rows_env == 32 ? rows_env : (tuning_shared() ? 32 : 16);
+    const int mt = (want == 32 && rows % 32 == 0 && !x_lo) ? 2 : 1;
     const int group = std::max(planes, std::min(KS_GROUP, group_env > 0 ? group_env : (tuning_shared() ? 3 : KS_GROUP)));
-    const int gcap = std::max(1, std::min(group / planes, per_wave));
-    const size_t lds = (size_t)KS_WAVES * 64 * 16 + (size_t)KS_WAVES * planes * gcap * 2048;
+    int gcap = std::max(1, std::min(group / planes, per_wave));
+    if (mt == 2) gcap = std::min(gcap, 3);  // 112 KB of LDS at most
+    dim3 grid(N / 16, rows / (16 * mt));
+    const size_t lds = (size_t)KS_WAVES * mt * 64 * 16 + (size_t)KS_WAVES * planes * gcap * mt * 2048;
     if (x_lo) {
         if (lds > 64 * 1024) raise_lds_limit((const void*)gemm_k_split_kernel<true>, 60);
         hipLaunchKernelGGL((gemm_k_split_kernel<true>), grid, dim3(64 * KS_WAVES), lds, st, w, x, N, K, ldx, x_lo, wpk, gcap, e);
+    } else if (mt == 2) {
+        if (lds > 64 * 1024) raise_lds_limit((const void*)gemm_k_split_kernel<false, 2>, 62);
+        hipLaunchKernelGGL((gemm_k_split_kernel<false, 2>), grid, dim3(64 * KS_WAVES), lds, st, w, x, N, K, ldx, 0L, wpk, gcap, e);
     } else {
         if (lds > 64 * 1024) raise_lds_limit((const void*)gemm_k_split_kernel<false>, 61);
         hipLaunchKernelGGL((gemm_k_split_kernel<false>), grid, dim3(64 * KS_WAVES), lds, st, w, x, N, K, ldx, 0L, wpk, gcap, e);
