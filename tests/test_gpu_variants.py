@@ -103,3 +103,17 @@ def test_units_reading_the_f32_stream_change_nothing():
         assert r.returncode == 0 and "wav " in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
         digests.append(r.stdout.split("wav ")[1].split()[0])
     assert digests[0] == digests[1]
+
+
+def test_k_split_row_tiles_change_nothing():
+    """Two 16-row token tiles per k_split block (the choice with several decode streams in flight) add the same products in
+    the same order as one tile per block: sampled bf16 codes of a 20-row batch are identical."""
+    script = MEMO_SCRIPT.replace("for i in range(5)]", "for i in range(20)]")
+    assert script != MEMO_SCRIPT
+    digests = []
+    for rows in ("16", "32"):
+        e = dict(os.environ, QTTS_TUNE="shared", QTTS_KS_ROWS=rows)
+        r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + script], env=e, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0 and "codes " in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+        digests.append(r.stdout.split("codes ")[1].split()[0])
+    assert digests[0] == digests[1]
