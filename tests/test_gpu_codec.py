@@ -83,8 +83,9 @@ def test_bf16_decode(bind, golden):
 
 @pytest.mark.parametrize("dtype,causal_db", [("bf16", 36.0), ("f32", 80.0)])
 def test_full_size_codec_properties(dtype, causal_db):
-    """Reference-default codec shapes (1024-wide transformer, 1536-channel vocoder, x1920 upsampling), sizes the
-    oracle cannot decode in seconds: causality (a prefix decodes to a prefix; in bf16 only down to the rounding
+    """Reference-default codec shapes (1024-wide transformer, 1536-channel vocoder, x1920 upsampling) through properties that
+    need no oracle (the oracle comparison at these shapes, rows of up to 104 frames, is in test_gpu_parity_full_size.py):
+    causality (a prefix decodes to a prefix; in bf16 only down to the rounding
     noise floor because the row count selects a different GEMM summation order), batch-row independence, chunked
     decode equals full decode on the first window, samples clamped to [-1, 1]."""
     import torch

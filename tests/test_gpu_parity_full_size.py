@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import SEED, snr_db
-from golden.make_golden import GREEDY
+from golden.make_golden import GREEDY, SAMPLED
 
 pytestmark = pytest.mark.gpu
 
@@ -48,8 +48,8 @@ def _pair(bind, shape, dtype, talker=True, codec=False):
     return m, o, cfg, ccfg, tmpl
 
 
-def _oracle_row(bind, o, cfg, text, frames, speaker="speaker1"):
-    return o.generate(text, bind.resolve_codec_prefill(cfg, "english", speaker), GREEDY, frames,
+def _oracle_row(bind, o, cfg, text, frames, speaker="speaker1", sampling=GREEDY, seed=0):
+    return o.generate(text, bind.resolve_codec_prefill(cfg, "english", speaker), sampling, frames, seed=seed,
                       speaker_token=bind.resolve_speaker_token(cfg, speaker), trace=True)
 
 
@@ -113,6 +113,74 @@ def test_headline_shape_f32_rows_of_a_batch_of_64():
         m.close()
 
 
+def test_headline_shape_f32_rows_at_the_benchmarked_context_lengths():
+    """1.7B-like model, f32, the benchmark's batch of 64 for 100 frames: prompts of 19 .. 75 positions grow past the 64-token
+    KV page twice (a row's cache then spans three pages).  Rows 0, 31 and 63 against the oracle run one utterance at a time:
+    code ids exact under the margin rule, logits within 1e-3 for as long as the histories agree."""
+    from oracle import bind
+    m, o, cfg, ccfg, tmpl = _pair(bind, "S17", "f32")
+    try:
+        frames = 100
+        texts, reqs = _batch64(tmpl)
+        out = m.generate(reqs, _greedy(), frames, trace=True)
+        graph = m.generate(reqs, _greedy(), frames)
+        assert np.array_equal(graph.codes, out.codes)
+        for b in (0, 31, 63):
+            ref = _oracle_row(bind, o, cfg, texts[b], frames)
+            assert ref["num_steps"] == frames
+            _check_f32_row(ref, out.codes[b], out.logits[b], f"S17 f32 row {b}, {frames} frames")
+    finally:
+        m.close()
+
+
+def test_headline_shape_f32_seeded_sampling_as_the_benchmark_draws():
+    """The benchmark's sampling mode at its shape: temperature 0.9, top-k 50 for the talker and the code predictor, one
+    MT19937 stream per utterance seeded 42 + u.  f32, rows 0, 31 and 63 of the batch of 64, 20 frames: every code id equals the
+    oracle's (the draw compares a 24-bit uniform with f32 running sums, so a difference needs a cumulative probability
+    within rounding of the uniform; none occurs on these rows)."""
+    from oracle import bind
+    from qwen3_tts_rs_amd import GenerationRequest, SamplingConfig
+    m, o, cfg, ccfg, tmpl = _pair(bind, "S17", "f32")
+    try:
+        frames = 20
+        texts, _ = _batch64(tmpl)
+        reqs = [GenerationRequest(text_ids=t, language="english", speaker="speaker1", seed=42 + u) for u, t in enumerate(texts)]
+        sc = SamplingConfig(**{k: SAMPLED[k] for k in SamplingConfig().__dict__ if k in SAMPLED})
+        out = m.generate(reqs, sc, frames)
+        eager = m.generate(reqs, sc, frames, use_graph=False)
+        assert np.array_equal(eager.codes, out.codes)
+        for b in (0, 31, 63):
+            ref = _oracle_row(bind, o, cfg, texts[b], frames, sampling=SAMPLED, seed=42 + b)
+            n = ref["num_steps"]
+            assert n == out.codes[b].shape[0] or n <= frames
+            assert np.array_equal(ref["codes"][:n], out.codes[b][:n]), (
+                f"row {b}: first difference at frame {int(np.argmin((ref['codes'][:n] == out.codes[b][:n]).all(axis=1)))}")
+    finally:
+        m.close()
+
+
+def test_headline_shape_bf16_logits_beyond_the_first_kv_page():
+    """bf16 decode attention over more than one KV page at the benchmarked shape: the longest prompts of the batch of 64 (75
+    positions) start their first frame on the second page.  Logits of those rows within 2e-2 of the oracle for as long as the
+    code histories agree."""
+    from oracle import bind
+    m, o, cfg, ccfg, tmpl = _pair(bind, "S17", "bf16")
+    try:
+        frames = 6
+        texts, reqs = _batch64(tmpl)
+        longest = sorted(range(64), key=lambda u: -len(texts[u]))[:2]
+        assert all(len(texts[u]) - 8 + 3 + 5 + 2 > 64 for u in longest)      # prompt positions: role + codec prefill + text + eos + bos
+        out = m.generate(reqs, _greedy(), frames, trace=True)
+        for b in longest:
+            ref = _oracle_row(bind, o, cfg, texts[b], frames)
+            same = (ref["codes"] == out.codes[b]).all(axis=1)
+            upto = min((int(np.argmin(same)) if not same.all() else frames) + 1, frames)
+            err = np.abs(ref["logits"][:upto] - out.logits[b][:upto]).max()
+            assert err <= BF16_LOGIT_TOL, f"row {b}: {err:.4f} over {upto} frames"
+    finally:
+        m.close()
+
+
 @pytest.mark.parametrize("with_session", [False, True], ids=["one-stream-kernels", "several-streams-kernels"])
 def test_headline_shape_bf16_logits_of_a_batch_of_64(with_session):
     """The benchmarked configuration itself (1.7B-like, bf16, 64 rows): logits of rows 0, 31 and 63 within max-abs 2e-2 of
@@ -155,14 +223,15 @@ def test_headline_shape_bf16_logits_of_a_batch_of_64(with_session):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_reference_default_codec_against_the_oracle(dtype):
-    """Reference-default codec shapes (1024-wide transformer, 1536-channel vocoder, x1920): two rows of 12 and 9 frames
-    against the oracle's decode of identical codes."""
+    """Reference-default codec shapes (1024-wide transformer, 1536-channel vocoder, x1920): rows of 104, 12 and 9 frames against
+    the oracle's decode of identical codes.  The long row crosses the 72-key attention window and spans two 64-query tiles of
+    the banded attention kernel."""
     from oracle import bind
     m, o, cfg, ccfg, tmpl = _pair(bind, "S17", dtype, talker=False, codec=True)
     try:
         rng = np.random.default_rng(5)
-        codes = rng.integers(0, 2048, (2, 12, 16)).astype(np.uint32)
-        lens = [12, 9]
+        codes = rng.integers(0, 2048, (3, 104, 16)).astype(np.uint32)
+        lens = [104, 12, 9]
         wavs = m.decode_codes(codes, lens)
         for b, L in enumerate(lens):
             ref = o.codec_decode(codes[b, :L])
