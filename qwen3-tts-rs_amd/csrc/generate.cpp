@@ -9,6 +9,7 @@
 // max_new_tokens frames is retired at the next poll and its slot is prefilled with the next queued utterance while the other
 // rows keep decoding; every utterance gets exactly the frames a batch of one would have produced for it).
 #include "generate.hpp"
+#include "cp_pass.hpp"
 #include "runner.hpp"
 
 #include <algorithm>
@@ -69,6 +70,8 @@ struct GenState {
     Workspace ws;                            // activation scratch shared by every layer
     DevBuf cp_in_t, cp_in_f, hid_scratch_f; // code-predictor inputs; rows [0,B) double as the talker's post-norm hidden
     DevBuf cp_qkv_in;                        // first-layer q|k|v rows gathered from the model's tables (CpMemo)
+    DevBuf cp_pass_ts;
+    DevBuf cp_pass;                          // flags and per-XCD activation buffers of the one-launch code-predictor pass
     DevBuf text_rows, extra, trailing, tts_pad_dummy;
     DevBuf ibuf;                             // int scratch: ids / descriptors
     DevBuf toks_prompt, tiles_prompt, toks_dec, toks_cp;
@@ -539,6 +542,54 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
         }
         g.cp_qkv_in.ensure((size_t)(B + 64) * cp_nqkv * 4);
     }
+    // ---- single-token passes as ONE launch each (k_cp_pass.hip) where the stack has the shape its work split is written for.
+    // Opt-in (QTTS_CP_PASS=1): measured 144 us per pass against 142 us for the five-launch layers on one stream (4.64 ms per frame
+    // either way), and 1326 against 1614 audio-s/s with two sessions in flight - its 256 resident workgroups hold half of every
+    // CU's registers while they wait for each other, which the other session's kernels then wait for.  Its workgroups wait for each
+    // other, so at most two such launches may be in flight on a GPU (two workgroups fit a CU): one handle + one session.
+    static const bool pass_on = getenv("QTTS_CP_PASS") && atoi(getenv("QTTS_CP_PASS")) == 1;
+    bool use_pass = use_memo && pass_on && !split_cp && B <= CP_PASS_ROWS && Hc == CP_PASS_H && c.cp.inter == CP_PASS_I && c.cp.nh == CP_PASS_NH &&
+                    c.cp.nkv == CP_PASS_NKV && c.cp.d == CP_PASS_D && c.cp.layers <= CP_PASS_MAX_LAYERS && c.cp.window == 0 && G <= 17 &&
+                    (Vc == 1024 || Vc == 2048 || Vc == 4096);
+    CpPassArgs pass{};
+    if (use_pass) {
+        for (int l = 0; l < c.cp.layers && use_pass; ++l) {
+            const LayerW& w = m.cp.layers[(size_t)l];
+            use_pass = w.qkv.packed && w.o.packed && w.gate_up_il.packed && w.down.packed;
+            pass.layer[l] = CpPassLayer{(const bf16_t*)w.qkv.p, (const bf16_t*)w.o.p, (const bf16_t*)w.gate_up_il.p, (const bf16_t*)w.down.p,
+                                        w.qkv_bias, w.o_bias, w.q_norm, w.k_norm, w.ln1, w.ln2};
+        }
+        for (int j = 1; j < G - 1 && use_pass; ++j) use_pass = m.cp_head[(size_t)j].packed;
+    }
+    if (use_pass) {
+        pass.layers = c.cp.layers; pass.final_norm = m.cp.final_norm; pass.V = Vc; pass.eps = c.cp.eps;
+        pass.scale = (float)std::pow((double)c.cp.d, -0.5);
+        pass.M = B; pass.x_in = g.ws.x.as<float>(); pass.qkv0 = g.cp_qkv_in.as<float>(); pass.kv = g.cp.kv;
+        pass.logits = g.ws.part.as<float>(); pass.ld_logits = Vc; pass.spin_limit = 1u << 22;
+        const size_t nb = cp_pass_scratch_bytes();
+        if (g.cp_pass.bytes < nb) {
+            g.cp_pass.alloc(nb);
+            QTTS_HIP(hipMemsetAsync(g.cp_pass.p, 0, nb, st));
+        }
+        cp_pass_bind_scratch(pass, g.cp_pass.p);
+        static const bool want_ts = getenv("QTTS_CP_PASS_TS") != nullptr;
+        if (want_ts) {
+            g.cp_pass_ts.ensure(256 * 8);
+            QTTS_HIP(hipMemsetAsync(g.cp_pass_ts.p, 0, 256 * 8, st));
+            pass.ts = g.cp_pass_ts.as<unsigned long long>();
+        }
+    }
+    // a wait between the workgroups of such a launch that timed out leaves its results and flags unusable
+    auto check_pass = [&]() {
+        if (!use_pass) return;
+        unsigned err = 0;
+        copy_sync(&err, pass.err, 4, hipMemcpyDeviceToHost, st);
+        if (err) {
+            QTTS_HIP(hipMemsetAsync(g.cp_pass.p, 0, CP_PASS_FLAG_BYTES, st));
+            QTTS_HIP(hipStreamSynchronize(st));
+            throw Error(ERR_HIP, "generate: the workgroups of a code-predictor pass stopped waiting for each other (the launch did not get the whole device)");
+        }
+    };
 
     // memo_table >= 0: the sampler also gathers the tabulated start of the next code-predictor pass for the code it drew
     auto sample = [&](const float* logits, int vocab, int gcol, bool talker, const void* next_table = nullptr, void* next_dst = nullptr,
@@ -610,11 +661,20 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
             for (int j = 1; j < G - 1; ++j) {  // code_predictor.rs:480-527
                 // pass input: the embedding row of code j (exact in the model dtype, no remainder plane) -> x, xn, ssA; or, tabulated,
                 // x and the first layer's q|k|v rows as the sampler gathered them
+                if (use_pass) {  // layers + final norm + head of this pass in one launch
+                    CpPassArgs pa = pass;
+                    pa.pos = j + 1; pa.ctx = j + 2;
+                    pa.cos = m.cp.cos.as<float>() + (size_t)(j + 1) * (c.cp.d / 2); pa.sin = m.cp.sin.as<float>() + (size_t)(j + 1) * (c.cp.d / 2);
+                    pa.head = (const bf16_t*)m.cp_head[(size_t)j].p;
+                    R.timed(B, Vc, Hc, [&] { launch_cp_pass(st, pa); });
+                    trace_cp(j);
+                } else {
                 if (!use_memo) nt = enter(g.ws.act.p, 0, g.ws.q.as<float>(), B);
                 R.uni_len = j + 2;  // every row: position j + 1, keys 0 .. j + 1 (what ct holds for this pass)
                 nt = R.stack_fused(m.cp, B, ct + 2 * B + (size_t)j * B, g.cp.kv, nt, true, use_memo ? g.cp_qkv_in.as<float>() : nullptr);
                 R.uni_len = 0;
                 head(j, 0, nt);
+                }
                 if (use_memo) sample(g.ws.part.as<float>(), Vc, j + 1, false, nullptr, nullptr, F32, j + 1 < G - 1 ? j : -1);
                 else sample(g.ws.part.as<float>(), Vc, j + 1, false, j + 1 < G - 1 ? m.cp_emb[(size_t)j] : nullptr, inj, in_dt);
             }
@@ -687,6 +747,7 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
             QTTS_HIP(hipMemcpyAsync(step_h.data(), g.step.p, (size_t)B * 4, hipMemcpyDeviceToHost, st));
         }
         QTTS_HIP(hipStreamSynchronize(st));
+        check_pass();
     };
     auto all_eos = [&]() {
         poll();
@@ -813,6 +874,15 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
         if (trace_l) copy_sync(dbg->logits, g.trace_logits.p, (size_t)B * max_new * V * 4, hipMemcpyDeviceToHost, st);
         if (trace_h) copy_sync(dbg->hidden, g.trace_hidden.p, (size_t)B * max_new * H * 4, hipMemcpyDeviceToHost, st);
         if (trace_c) copy_sync(dbg->cp_logits, g.trace_cp.p, (size_t)B * max_new * (G - 1) * Vc * 4, hipMemcpyDeviceToHost, st);
+    }
+    if (use_pass && pass.ts) {  // marks of the last pass of the last frame
+        std::vector<unsigned long long> h(256);
+        copy_sync(h.data(), pass.ts, 256 * 8, hipMemcpyDeviceToHost, st);
+        for (int w = 0; w < 2; ++w) {
+            fprintf(stderr, "cp_pass marks, workgroup %d (us since the first):", w ? 255 : 0);
+            for (int i = 0; i < 128 && h[(size_t)w * 128 + i]; ++i) fprintf(stderr, " %.2f", (double)(h[(size_t)w * 128 + i] - h[0]) * 0.01);
+            fprintf(stderr, "\n");
+        }
     }
     float ms01 = 0, ms12 = 0;
     QTTS_HIP(hipEventElapsedTime(&ms01, ev0, ev1));
