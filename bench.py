@@ -162,6 +162,44 @@ def cpu_baseline(args, cfg, ccfg, tmpl):
                       f"generate {t1 - t0:.2f} s, codec {t2 - t1:.2f} s"}
 
 
+def pin_near_gpu(local: int):
+    """Keeps this rank's host threads (one per decode session) on the CPUs of its GPU's NUMA node when the machine has more than
+    one node and the process is allowed to run there.  Returns the node, or None when nothing was changed."""
+    try:
+        import glob
+        import torch
+        if len(glob.glob("/sys/devices/system/node/node[0-9]*")) < 2:
+            return None
+        pr = torch.cuda.get_device_properties(local)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        allowed = cpus & os.sched_getaffinity(0)
+        if len(allowed) < 4:          # a cpuset that leaves almost nothing of that node: stay where we are
+            return None
+        os.sched_setaffinity(0, allowed)
+        return node
+    except Exception:
+        return None
+
+
+def gather_ranks(values, dist, device: str):
+    """values: this rank's [elapsed_s, audio_s, utterances, frames] -> the same for every rank (list of lists), so that a
+    scaling result below N x can be told apart: imbalance (audio per rank) or host contention (time per rank)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [list(values)]
+    import torch
+    mine = torch.tensor(values, dtype=torch.float64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [[float(v) for v in t] for t in out]
+
+
 def reduce_job(elapsed: float, audio_s: float, dist, device: str):
     """Whole-job aggregate over ranks: (slowest rank's time, audio seconds of all ranks).  The only collective of the path."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
@@ -187,9 +225,15 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     # QTTS_BENCH_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks then share devices)
     backend = os.environ.get("QTTS_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
     if backend != "nccl":
-        local = local % torch.cuda.device_count()
+        local = local % max(ndev, 1)
+    if local >= ndev:
+        print(f"bench.py: rank {rank} has LOCAL_RANK={local} but this node shows {ndev} GPU(s): one rank per GPU is needed "
+              f"(QTTS_BENCH_BACKEND=gloo lets ranks share devices for a rehearsal)", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local)
+    pinned = pin_near_gpu(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -215,7 +259,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    stats = dict(prefill_ms=0.0, frames_ms=0.0, frames=0, codec_ms=0.0, audio_s=0.0, step_ms=[], first_ms=[], launch_host_ms=0.0)
+    stats = dict(prefill_ms=0.0, frames_ms=0.0, frames=0, codec_ms=0.0, audio_s=0.0, step_ms=[], first_ms=[], launch_host_ms=0.0, utterances=0)
     out_last = [None]
     lock = threading.Lock()
 
@@ -256,6 +300,7 @@ def main():
                 stats["launch_host_ms"] += mod.last_timing["graph_launch_host_ms"]
                 stats["codec_ms"] += 0.0 if args.no_codec else mod.codec_device_ms()
                 stats["audio_s"] += sum(out.effective_lengths) * FRAME_SECONDS
+                stats["utterances"] += len(out.effective_lengths)
                 stats["step_ms"].append((time.perf_counter() - t_s) * 1e3)
                 stats["first_ms"].append(first_ms[0] if first_ms else stats["step_ms"][-1])
                 out_last[0] = out
@@ -317,7 +362,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    elapsed_max, audio_total = reduce_job(elapsed, stats["audio_s"], dist if world > 1 else None, f"cuda:{local}" if backend == "nccl" else "cpu")
+    rdev = f"cuda:{local}" if backend == "nccl" else "cpu"
+    elapsed_max, audio_total = reduce_job(elapsed, stats["audio_s"], dist if world > 1 else None, rdev)
+    per_rank = gather_ranks([elapsed, stats["audio_s"], stats["utterances"], stats["frames"]], dist if world > 1 else None, rdev)
     if strong and args.dump_codes:
         from qwen3_tts_rs_amd.shard import gather_results
         got = gather_results(sorted(codes_crc), [codes_crc[u] for u in sorted(codes_crc)], args.utterances, dist if world > 1 else None)
@@ -339,13 +386,19 @@ def main():
         # HBM-side bytes of one frame from the PMC counters: collected once per round with tools/dev/pmc_frame.sh (rocprofv3 cannot
         # follow a hipGraph, so the passes run the frame eagerly), committed under profiles/ and quoted here when this run is the
         # configuration they were taken on (bench_data/ travels with the tree to the GPU box, profiles/ does not)
-        traffic = None
-        tpath = os.path.join(ROOT, "bench_data", "r02_frame_traffic.json")   # a copy lives under profiles/
+        # The figure is quoted only for the kernel selection the counters were taken on ("alone": one stream; "shared": the
+        # kernels picked for several streams in flight, which is what P > 1 runs), and says where it comes from.
+        traffic, traffic_ref = None, None
+        tpath = os.path.join(ROOT, "bench_data", "frame_traffic.json")   # a copy lives under profiles/
         if os.path.exists(tpath) and args.shape == "S17" and args.batch == 64 and args.dtype == "bf16" and not strong:
-            traffic = json.load(open(tpath)).get("traffic_bytes")
+            tj = json.load(open(tpath)).get("shared" if P > 1 else "alone")
+            if tj:
+                traffic = tj.get("traffic_bytes")
+                traffic_ref = {"bytes": traffic, "kernel_selection": "shared" if P > 1 else "alone", "measured": tj.get("measured"),
+                               "how": "rocprofv3 --pmc passes over eagerly launched frames of one stream (tools/dev/pmc_frame.sh)"}
         roofline = {"bound": "hbm", "kernel": "decode frame (one hipGraph launch: talker step + code-predictor passes + sampling)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "bytes_per_launch": bytes_frame, "avg_launch_ms": round(ms_per_frame, 4),
+                    "traffic": traffic, "traffic_reference": traffic_ref, "bytes_per_launch": bytes_frame, "avg_launch_ms": round(ms_per_frame, 4),
                     "launches": frames_run, "streams_in_flight": P,
                     "note": "achieved = algorithmic bytes of every decode frame in the timed region / wall time of the region "
                             "(includes the overlapped prefill and codec phases); avg_launch_ms is per stream",
@@ -387,7 +440,7 @@ def main():
             # HBM-side bytes of the decode from the PMC counters (tools/dev/pmc_codec.sh: 16 x 375 frames, scaled by the frames
             # decoded here: every stage's traffic is proportional to them), quoted for the shapes the passes were taken on
             ctraffic = None
-            cpath = os.path.join(ROOT, "bench_data", "r02_codec_traffic.json")   # a copy lives under profiles/
+            cpath = os.path.join(ROOT, "bench_data", "codec_traffic.json")   # a copy lives under profiles/
             if os.path.exists(cpath) and args.shape == "S17" and args.dtype == "bf16":
                 ct = json.load(open(cpath))
                 ctraffic = round(ct["traffic_bytes"] * sum(out_last[0].effective_lengths) / float(ct["batch"] * ct["frames"]))
@@ -424,6 +477,8 @@ def main():
             "ms_per_frame": round(ms_per_frame, 4),
             "graph_launch_host_ms_per_frame": round(stats["launch_host_ms"] / frames_run, 4),
             "roofline": roofline, "roofline_gemm": gemm, "roofline_codec": codec, "cpu_baseline": cpu,
+            # per rank: [seconds in the timed region, audio seconds produced, utterances, decode frames]; numa_node: where rank 0 pinned itself
+            "per_rank": [[round(v, 3) for v in r] for r in per_rank], "numa_node": pinned,
         }
     for mod in reversed(models):   # sessions before the model they borrow from
         mod.close()

@@ -105,8 +105,10 @@ typedef struct {
 /* SamplingConfig (nn/sampling.rs:13-64) as merged by GenerateConfig::merge (model/config.rs:128-157).  The floating
  * point fields are f64 as in the reference and are narrowed exactly where it narrows them: (1 / temperature) as f32
  * (nn/sampling.rs:199-204), top_p as f32, repetition_penalty as f32.  min_new_tokens: frames during which EOS stays
- * suppressed (nn/sampling.rs:28-29,55: the reference's default is 2; 0 lets a row end on its first frame, and when every
- * row does, num_steps is 0 as in nn/generation.rs:939,1145-1150). */
+ * suppressed (nn/sampling.rs:28-29,55).  A NEGATIVE value asks for the reference's default, 2 (what ConditionalGeneration::generate
+ * sets: nn/generation.rs:841-842); 0 lets a row end on its first frame, and when every row does, num_steps is 0 as in
+ * nn/generation.rs:939,1145-1150.  A zero-initialised struct therefore does NOT give the reference's behaviour: set the
+ * field to -1 (or 2) for that. */
 typedef struct {
     double temperature;
     int top_k;
@@ -224,12 +226,13 @@ int qtts_encode_audio(qtts_model* m, const float* audio, const int* n_samples, i
  * (model/mod.rs:520-528): audio [B][max_samples] f32 @ 24 kHz -> mel_out [B][frames_stride][128]. */
 int qtts_mel(qtts_model* m, const float* audio, const int* n_samples, int B, int max_samples, float* mel_out,
              int frames_stride, int* n_frames);
-/* qtts_mel for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc).  No counterpart in the reference.  Same arguments and results as qtts_mel, but the device-side staging
+/* qtts_mel for callers that cannot allocate device memory (tight serving loops, harnesses that forbid hipMalloc, processes
+ * whose other streams are being captured into HIP graphs: an allocation synchronises the device; the call itself copies from
+ * pageable host memory and waits for its stream, so it is not meant to be captured).  No counterpart in the reference.  Same arguments and results as qtts_mel, but the device-side staging
  * of the clips, their lengths and the result lives in one fixed array per GPU (qtts_mel_noalloc_capacity() bytes, 16 MiB)
  * instead of buffers grown on demand: the call issues no hipMalloc / hipFree.  It fails with QTTS_ERR_SHAPE when
- * pad256(4 B) + pad256(4 B max_samples) + 512 B frames_stride exceeds that capacity.  Calls on one GPU share the array:
- * they must not overlap in time. */
+ * pad256(4 B) + pad256(4 B max_samples) + 512 B frames_stride exceeds that capacity.  Calls on one GPU share the array: the
+ * library makes them take turns (one lock per GPU, whatever model or session they come through). */
 int qtts_mel_noalloc(qtts_model* m, const float* audio, const int* n_samples, int B, int max_samples, float* mel_out,
                      int frames_stride, int* n_frames);
 int64_t qtts_mel_noalloc_capacity(void);

@@ -1,9 +1,7 @@
 // C ABI of libqtts_hip (declared in include/qtts.h).  Exceptions never cross the boundary: they are
 // mapped to the negative error classes and a thread-local message.
 #include <atomic>
-#include <chrono>
 #include <cstring>
-#include <thread>
 #include <memory>
 #include <string>
 #include <vector>
@@ -85,7 +83,12 @@ int qtts_init(int device_ordinal, qtts_ctx** out) {
     std::unique_ptr<qtts_ctx> c(new qtts_ctx());
     c->c.device = device_ordinal;
     QTTS_HIP(create_stream(&c->c.stream));
-    (void)mel_scratch(device_ordinal);  // device address of this GPU's fixed staging array (qtts_mel_noalloc)
+    try {
+        (void)mel_scratch(device_ordinal);  // device address of this GPU's fixed staging array (qtts_mel_noalloc)
+    } catch (...) {
+        (void)hipStreamDestroy(c->c.stream);
+        throw;
+    }
     *out = c.release();
     QTTS_API_END
 }
@@ -309,109 +312,6 @@ int qtts_bench_gemm(qtts_ctx* ctx, int dtype, int M, int N, int K, int KS, int i
     float ms = 0;
     QTTS_HIP(hipEventElapsedTime(&ms, e0, e1));
     *avg_us = (double)ms * 1000.0 / iters;
-    QTTS_API_END
-}
-
-// Callers that run qtts_bench_sync from several host threads at once (one context each) set the number of threads here;
-// every call then waits, graph instantiated, until all of them are ready, so that the timed launches overlap on the GPU.
-static std::atomic<int> g_sync_expected{0}, g_sync_arrived{0};
-void qtts_bench_sync_threads(int n) {
-    g_sync_arrived.store(0);
-    g_sync_expected.store(n);
-}
-static void bench_rendezvous() {
-    const int n = g_sync_expected.load();
-    if (n <= 1) return;
-    const int ticket = g_sync_arrived.fetch_add(1) + 1;
-    const int target = (ticket + n - 1) / n * n;  // calls come in rounds of n
-    const auto t0 = std::chrono::steady_clock::now();
-    while (g_sync_arrived.load() < target && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(20)) std::this_thread::yield();
-}
-
-// mode 0: `iters` iterations of two grid barriers inside one resident grid of `blocks` x `threads`; avg_us is per barrier and
-// *errors counts visibility failures / aborted waits.  mode 1: a hipGraph of `iters` empty kernels; avg_us per kernel node.
-int qtts_bench_sync(qtts_ctx* ctx, int mode, int blocks, int threads, int iters, double* avg_us, int* errors) {
-    QTTS_API_BEGIN
-    QTTS_CHECK(ctx && avg_us && errors && iters >= 1, ERR_BAD_ARG, "qtts_bench_sync: bad argument");
-    QTTS_HIP(hipSetDevice(ctx->c.device));
-    hipStream_t st = ctx->c.stream;
-    ScopedEvent e0, e1;
-    float ms = 0;
-    *errors = 0;
-    if (mode == 0) {
-        int dev_cus = 0;
-        QTTS_HIP(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, ctx->c.device));
-        QTTS_CHECK(blocks <= dev_cus * (threads <= 512 ? 2 : 1), ERR_SHAPE, "qtts_bench_sync: grid would not be co-resident");
-        DevBuf state;
-        state.alloc((size_t)(64 + blocks) * 4 + 1024);
-        for (int rep = 0; rep < 2; ++rep) {  // first run warms up
-            QTTS_HIP(hipMemsetAsync(state.p, 0, (size_t)(64 + blocks) * 4 + 1024, st));
-            QTTS_HIP(hipEventRecord(e0, st));
-            launch_barrier_bench(st, state.as<unsigned>(), blocks, threads, iters);
-            QTTS_HIP(hipEventRecord(e1, st));
-            QTTS_HIP(hipStreamSynchronize(st));
-        }
-        QTTS_HIP(hipEventElapsedTime(&ms, e0, e1));
-        unsigned h[32];
-        QTTS_HIP(hipMemcpy(h, state.p, sizeof(h), hipMemcpyDeviceToHost));
-        *errors = (int)h[17] + (h[16] ? 1000000 : 0);
-        *avg_us = (double)ms * 1e3 / (2.0 * iters);
-    } else if (mode >= 2) {
-        // mode 2/3/4: graph of `iters` dependent kernels (plain / 16-byte write-through / 8-byte write-through stores) over
-        // `threads` KiB of floats with `blocks` blocks; *errors != 0 when the final values are not `iters` (visibility failure)
-        const int n = threads * 256;
-        DevBuf a, b;
-        a.alloc((size_t)n * 4);
-        b.alloc((size_t)n * 4);
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        QTTS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-        for (int i = 0; i < iters; ++i) {
-            const float* src = (i & 1) ? b.as<float>() : a.as<float>();
-            float* dst = (i & 1) ? a.as<float>() : b.as<float>();
-            if (mode == 5 && (i & 1)) launch_chain_b(st, src, dst, n, blocks);   // mode 5: alternate two different kernels
-            else launch_chain(st, src, dst, n, blocks, mode == 5 ? 0 : mode - 2);
-        }
-        QTTS_HIP(hipStreamEndCapture(st, &graph));
-        QTTS_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        QTTS_HIP(hipGraphDestroy(graph));
-        bench_rendezvous();
-        for (int rep = 0; rep < 2; ++rep) {
-            QTTS_HIP(hipMemsetAsync(a.p, 0, (size_t)n * 4, st));
-            QTTS_HIP(hipEventRecord(e0, st));
-            QTTS_HIP(hipGraphLaunch(exec, st));
-            QTTS_HIP(hipEventRecord(e1, st));
-            QTTS_HIP(hipStreamSynchronize(st));
-        }
-        QTTS_HIP(hipEventElapsedTime(&ms, e0, e1));
-        (void)hipGraphExecDestroy(exec);
-        std::vector<float> h((size_t)n);
-        QTTS_HIP(hipMemcpyAsync(h.data(), (iters & 1) ? b.p : a.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-        QTTS_HIP(hipStreamSynchronize(st));
-        bench_rendezvous();  // nobody starts the next capture while another thread still copies
-        int bad = 0;
-        for (int i = 0; i < n; ++i) bad += h[(size_t)i] != (float)iters;
-        *errors = bad;
-        *avg_us = (double)ms * 1e3 / iters;
-    } else {
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        QTTS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
-        for (int i = 0; i < iters; ++i) launch_null(st);
-        QTTS_HIP(hipStreamEndCapture(st, &graph));
-        QTTS_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        QTTS_HIP(hipGraphDestroy(graph));
-        bench_rendezvous();
-        for (int rep = 0; rep < 2; ++rep) {
-            QTTS_HIP(hipEventRecord(e0, st));
-            QTTS_HIP(hipGraphLaunch(exec, st));
-            QTTS_HIP(hipEventRecord(e1, st));
-            QTTS_HIP(hipStreamSynchronize(st));
-        }
-        QTTS_HIP(hipEventElapsedTime(&ms, e0, e1));
-        (void)hipGraphExecDestroy(exec);
-        *avg_us = (double)ms * 1e3 / iters;
-    }
     QTTS_API_END
 }
 

@@ -234,6 +234,7 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
     const int H = c.talker.hidden, Ht = c.text_hidden, G = c.groups, V = c.vocab, Vc = c.cp_vocab, Hc = c.cp.hidden;
     if (!m.gen) m.gen.reset(new GenState());
     GenState& g = *m.gen;
+    m.tuning->latch(TUNE_ALONE);  // first generate call of a weight set without sessions: kernels picked for one stream (kernels.hpp)
     Runner R(m, g.ws, &g.timer);
     hipStream_t st = R.st;
     const int dt = m.dtype;
@@ -613,7 +614,7 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
         a.suppress_hi = talker ? V : 0;
         a.eos_id = talker ? c.eos : -1;
         // sampling.rs:28-29 via generation.rs:841-842; subtalker: sampling.rs:117
-        a.min_new_tokens = talker ? (dbg && dbg->min_new_tokens > 0 ? dbg->min_new_tokens : std::max(0, sp->min_new_tokens)) : 0;
+        a.min_new_tokens = talker ? (dbg && dbg->min_new_tokens > 0 ? dbg->min_new_tokens : (sp->min_new_tokens < 0 ? 2 : sp->min_new_tokens)) : 0;
         a.step = d_step; a.active = g.active.as<int>(); a.max_steps = max_new; a.uniforms = g.uniforms.as<float>(); a.codes_base = g.codes.as<unsigned>(); a.row_stride = row_stride;
         a.G = G; a.g = gcol; a.eos_step = talker ? g.eos_step.as<int>() : nullptr;
         launch_sample(st, a);

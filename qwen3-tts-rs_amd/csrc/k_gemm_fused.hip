@@ -683,25 +683,23 @@ bool gemm_stream_fits(int M, int N, int K, bool lo) {
 // Measured at 64 rows (us per launch, weights streamed from HBM): N = 12288, K = 2048, two planes: 17.9 against 34.6 for the
 // whole-K tile kernel and 23.8 + 5.3 for split-K slabs + the SwiGLU pass; N = 4096: 12.8 against 10.4 (64 blocks are too few);
 // K = 1024: the whole-K kernel wins at every N.  QTTS_GEMM_STREAM: 0 never, 1 (default) by this rule, 2 whenever it fits.
-bool gemm_stream_preferred(int M, int N, int K, bool lo) {
+bool gemm_stream_preferred(int M, int N, int K, bool lo, bool shared) {
     static const int mode = getenv("QTTS_GEMM_STREAM") ? atoi(getenv("QTTS_GEMM_STREAM")) : 1;
     if (mode == 0 || !gemm_stream_fits(M, N, K, lo)) return false;
     if (mode >= 2) return true;
-    // several streams in flight: wherever it fits (see tuning_shared in kernels.hpp; in the whole job that beats keeping the
-    // whole-K tile for the code predictor's q|k|v and heads, 2000 against 1954 audio-s/s without the codec)
-    if (tuning_shared()) return true;
+    // several streams in flight: wherever it fits (in the whole job that beats keeping the whole-K tile for the code predictor's
+    // q|k|v and heads, 2000 against 1954 audio-s/s without the codec)
+    if (shared) return true;
     return K == 2048 && N >= 8192;
 }
 
-static std::atomic<int> g_open_sessions{0};
-void tuning_sessions_changed(int delta) { g_open_sessions.fetch_add(delta); }
-bool tuning_shared() {
+int tuning_forced() {
     static const int forced = [] {
         const char* v = getenv("QTTS_TUNE");
-        if (!v) return -1;
-        return std::string(v) == "shared" ? 1 : (std::string(v) == "alone" ? 0 : -1);
+        if (!v) return (int)TUNE_UNSET;
+        return std::string(v) == "shared" ? (int)TUNE_SHARED : (std::string(v) == "alone" ? (int)TUNE_ALONE : (int)TUNE_UNSET);
     }();
-    return forced >= 0 ? forced == 1 : g_open_sessions.load() > 0;
+    return forced;
 }
 
 template <int MODE, bool LO, int NP>
@@ -747,7 +745,7 @@ void launch_gemm_stream(hipStream_t st, WMat Wm, const void* X, int ldx, long x_
 
 int fused_resid_tiles(int N) { return N / 16; }
 
-void launch_gemm_k_split(hipStream_t st, WMat Wm, const void* X, int ldx, long x_lo, int M, int N, int K, const FusedEpi& e) {
+void launch_gemm_k_split(hipStream_t st, WMat Wm, const void* X, int ldx, long x_lo, int M, int N, int K, const FusedEpi& e, bool shared) {
     QTTS_CHECK(M >= 1 && N % 16 == 0 && K % CHUNK == 0, ERR_SHAPE, "gemm_k_split: N must be a multiple of 16 and K of 64");
     QTTS_CHECK(e.mode == FUSED_RESID && e.x_out && e.xb_out && e.nw && e.ss_out && e.ss_ld >= fused_rows(M), ERR_BAD_ARG,
                "gemm_k_split: missing residual outputs");
@@ -764,9 +762,9 @@ void launch_gemm_k_split(hipStream_t st, WMat Wm, const void* X, int ldx, long x
     // fragments: half the weight reads through the L1s and half the blocks; 4.82 against 4.69 ms per frame alone, 1953 against
     // 1924 audio-s/s without the codec with three sessions).  QTTS_KS_ROWS=16 / 32 forces either.
     static const int rows_env = getenv("QTTS_KS_ROWS") ? atoi(getenv("QTTS_KS_ROWS")) : 0;
-    const int want = rows_env == 16 || rows_env == 32 ? rows_env : (tuning_shared() ? 32 : 16);
+    const int want = rows_env == 16 || rows_env == 32 ? rows_env : (shared ? 32 : 16);
     const int mt = (want == 32 && rows % 32 == 0 && !x_lo) ? 2 : 1;
-    const int group = std::max(planes, std::min(KS_GROUP, group_env > 0 ? group_env : (tuning_shared() ? 3 : KS_GROUP)));
+    const int group = std::max(planes, std::min(KS_GROUP, group_env > 0 ? group_env : (shared ? 3 : KS_GROUP)));
     int gcap = std::max(1, std::min(group / planes, per_wave));
     if (mt == 2) gcap = std::min(gcap, 3);  // 112 KB of LDS at most
     dim3 grid(N / 16, rows / (16 * mt));

@@ -61,11 +61,14 @@ void launch_gemm_rows(hipStream_t st, int dtype, WMat W, const void* X, float* o
 // (us per launch overall, 64 rows): talker q|k|v 4096 x 2048 - whole-K tile 10.1 / 8.75, K-streaming kernel 12.8 / 5.16;
 // code-predictor gate|up 6144 x 1024 - 7.1 / 3.82 against 7.8 / 3.08; k_split at K = 3072 with six X chunks per request
 // 6.0 / 3.78, with three 6.2 / 2.75.  In the whole three-session job: 1832 audio-s/s (no codec) with the kernels picked for one
-// stream, 2000 with the K-streaming kernel wherever it fits and three chunks per k_split request.  tuning_shared() is true while a session of any model is open (QTTS_TUNE=alone / shared
-// forces it); the pickers below read it at launch time, i.e. when a generate call captures its frame graph.  Results of bf16 runs
-// differ between the two choices by summation order only (within the same bounds against a CPU evaluation); f32 runs do not use these kernels.
-void tuning_sessions_changed(int delta);
-bool tuning_shared();
+// stream, 2000 with the K-streaming kernel wherever it fits and three chunks per k_split request.
+// The choice belongs to a weight set (a model and its sessions) and is made ONCE, by whichever comes first: opening a session
+// (several streams) or the first generate call (one stream); QTTS_TUNE=alone / shared forces it for every model.  It never
+// changes afterwards, so a request's tokens do not depend on what else is open in the process.  Results of bf16 runs differ
+// between the two choices by summation order only (within the same bounds against a CPU evaluation); f32 runs do not use
+// these kernels.
+enum { TUNE_UNSET = -1, TUNE_ALONE = 0, TUNE_SHARED = 1 };
+int tuning_forced();  // QTTS_TUNE: TUNE_ALONE / TUNE_SHARED, or TUNE_UNSET when the variable does not force a choice
 
 // ---- k_gemm_fused.hip: decode GEMMs that own finished outputs and apply the consumer's element-wise work (bf16, hidden <= 1024)
 enum { FUSED_PLAIN = 0, FUSED_SWIGLU = 1, FUSED_RESID = 2 };
@@ -98,17 +101,13 @@ bool full_k_fits(int K, bool lo);
 void launch_gemm_full_k(hipStream_t st, WMat W, const void* X, int ldx, long x_lo, int M, int N, int K, const FusedEpi& e);
 // same contract as full_k for 64-row multiples and K = 1024 or 2048: K is walked in double-buffered phases inside the block
 bool gemm_stream_fits(int M, int N, int K, bool lo);
-bool gemm_stream_preferred(int M, int N, int K, bool lo);  // it fits and is the faster kernel for the shape
+bool gemm_stream_preferred(int M, int N, int K, bool lo, bool shared);  // it fits and is the faster kernel for the shape (shared: several decode streams in flight)
 void launch_gemm_stream(hipStream_t st, WMat W, const void* X, int ldx, long x_lo, int M, int N, int K, const FusedEpi& e);
-void launch_gemm_k_split(hipStream_t st, WMat W, const void* X, int ldx, long x_lo, int M, int N, int K, const FusedEpi& e);
+void launch_gemm_k_split(hipStream_t st, WMat W, const void* X, int ldx, long x_lo, int M, int N, int K, const FusedEpi& e, bool shared = false);
 
 // ---- k_bench.hip (diagnostics)
 void launch_stream(hipStream_t st, const void* src, unsigned* sink, long bytes, int blocks, int pattern, int unroll, int ld_bytes);
 
-void launch_barrier_bench(hipStream_t st, unsigned* state, int blocks, int threads, int iters);
-void launch_null(hipStream_t st);
-void launch_chain(hipStream_t st, const float* in, float* out, int n, int blocks, int mode);
-void launch_chain_b(hipStream_t st, const float* in, float* out, int n, int blocks);
 
 // ---- k_elem.hip
 // x = [resid] + [scale *] (sum_ks part[ks] + [bias]); resid_out = x (f32, may alias resid); xn = rmsnorm(x) * w -> dtype;

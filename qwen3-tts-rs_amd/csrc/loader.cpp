@@ -19,6 +19,8 @@
 #include "json_min.hpp"
 #include "loader.hpp"
 
+#include <cmath>
+
 namespace qtts {
 
 namespace {
@@ -105,21 +107,36 @@ int load_file(Model& m, const std::string& path, bool load_encoder) {
         const Json& sh = t.at("shape");
         const Json& off = t.at("data_offsets");
         QTTS_CHECK(sh.kind == Json::Arr && off.kind == Json::Arr && off.arr.size() == 2, ERR_IO, "bad safetensors entry " + key);
+        // header numbers come from the file: only exact non-negative integers below 2^53 are taken, products are checked
+        auto as_count = [&](const Json& v, int64_t& out) {
+            if (v.kind != Json::Num || !(v.num >= 0.0) || v.num > 9007199254740992.0 || v.num != std::floor(v.num)) return false;
+            out = (int64_t)v.num;
+            return true;
+        };
         std::vector<int64_t> shape;
         int64_t n = 1;
+        bool ok = true;
         for (const Json& d : sh.arr) {
-            shape.push_back((int64_t)d.num);
-            n *= (int64_t)d.num;
+            int64_t dim = 0;
+            ok = ok && as_count(d, dim) && !__builtin_mul_overflow(n, dim, &n);
+            shape.push_back(dim);
         }
-        const size_t b = (size_t)off.arr[0].num, e = (size_t)off.arr[1].num;
+        int64_t b64 = 0, e64 = 0, nbytes = 0;
+        ok = ok && as_count(off.arr[0], b64) && as_count(off.arr[1], e64);
         const size_t es = dt == "F32" ? 4 : ((dt == "BF16" || dt == "F16") ? 2 : 0);
         if (es == 0) continue;  // integer / bool bookkeeping tensors: nothing on the path reads one
-        QTTS_CHECK(b <= e && e <= data_n && e - b == (size_t)n * es, ERR_IO, "tensor " + key + " does not match its data range");
+        ok = ok && !__builtin_mul_overflow(n, (int64_t)es, &nbytes);
+        QTTS_CHECK(ok, ERR_IO, "bad shape or data offsets for tensor " + key + " in " + path);
+        const size_t b = (size_t)b64, e = (size_t)e64;
+        QTTS_CHECK(b <= e && e <= data_n && e - b == (size_t)nbytes, ERR_IO, "tensor " + key + " does not match its data range");
         if (shape.empty()) shape.push_back(1);  // a scalar is a vector of one
         if (dt == "F16") {
             widened.resize((size_t)n);
-            const uint16_t* s = (const uint16_t*)(data + b);
-            for (int64_t i = 0; i < n; ++i) widened[(size_t)i] = f16_to_f32(s[i]);
+            for (int64_t i = 0; i < n; ++i) {
+                uint16_t h;  // the data section starts wherever the header ends: no alignment to rely on
+                std::memcpy(&h, data + b + (size_t)i * 2, 2);
+                widened[(size_t)i] = f16_to_f32(h);
+            }
             m.load_tensor(key, widened.data(), F32, shape.data(), (int)shape.size(), false);
         } else {
             m.load_tensor(key, data + b, dt == "F32" ? F32 : BF16, shape.data(), (int)shape.size(), false);
@@ -154,8 +171,15 @@ void load_model_dir(Model& m, const std::string& dir, bool load_tokenizer, bool 
         main = dir + "/" + shards[0];
     }
     load_file(m, main, load_encoder);
-    const std::string tok = dir + "/speech_tokenizer/model.safetensors";
-    if (codec && file_exists(tok)) load_file(m, tok, load_encoder);
+    if (codec) {  // find_tokenizer_weights_file (model/loader.rs:241-257): the first of these that exists
+        for (const char* cand : {"speech_tokenizer/model.safetensors", "tokenizer.safetensors", "audio_tokenizer.safetensors", "tokenizer/model.safetensors"}) {
+            const std::string tok = dir + "/" + cand;
+            if (file_exists(tok)) {
+                load_file(m, tok, load_encoder);
+                break;
+            }
+        }
+    }
     m.finalize();
 }
 

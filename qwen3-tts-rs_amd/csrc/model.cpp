@@ -9,9 +9,7 @@
 namespace qtts {
 
 Model::Model() = default;
-Model::~Model() {
-    if (is_view && finalized) tuning_sessions_changed(-1);
-}
+Model::~Model() = default;
 
 static StackCfg stack_from(const Json& j, int def_layers, int def_inter, int def_nkv) {
     StackCfg s;
@@ -334,6 +332,8 @@ void Model::init_view(const Model& base) {
     is_view = true;
     locks = base.locks;
     cp_memo = base.cp_memo;
+    tuning = base.tuning;
+    tuning->latch(TUNE_SHARED);  // a session is opened: unless its first generate call came earlier, this weight set decodes with the kernels picked for several streams
     dtype = base.dtype;
     cfg = base.cfg;
     codec = base.codec;
@@ -348,7 +348,7 @@ void Model::init_view(const Model& base) {
     cp_head = base.cp_head;
     if (!cp_emb.empty()) {
         cp_emb_ptrs.alloc(cp_emb.size() * sizeof(void*));
-        QTTS_HIP(hipMemcpy(cp_emb_ptrs.p, cp_emb.data(), cp_emb.size() * sizeof(void*), hipMemcpyHostToDevice));
+        copy_sync(cp_emb_ptrs.p, cp_emb.data(), cp_emb.size() * sizeof(void*), hipMemcpyHostToDevice, ctx->stream);
     }
     codec_state = base.codec_state;
     spk_state = base.spk_state;
@@ -358,7 +358,6 @@ void Model::init_view(const Model& base) {
         ensure_rope(cp, 64);
     }
     finalized = true;
-    tuning_sessions_changed(+1);  // decode kernels are picked for several streams in flight from now on
 }
 
 void Model::finalize() {
@@ -391,7 +390,7 @@ void Model::finalize() {
             cp_head.push_back(pack_raw(*this, h, release));
         }
         cp_emb_ptrs.alloc(cp_emb.size() * sizeof(void*));
-        QTTS_HIP(hipMemcpy(cp_emb_ptrs.p, cp_emb.data(), cp_emb.size() * sizeof(void*), hipMemcpyHostToDevice));
+        copy_sync(cp_emb_ptrs.p, cp_emb.data(), cp_emb.size() * sizeof(void*), hipMemcpyHostToDevice, ctx->stream);
         if (Hc != H) {  // code_predictor.rs:218-226
             expect_shape(get("talker.code_predictor.small_to_mtp_projection.weight"), "small_to_mtp_projection.weight", {Hc, H});
             proj = pack_raw(*this, "talker.code_predictor.small_to_mtp_projection.weight", release);

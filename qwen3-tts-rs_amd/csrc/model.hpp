@@ -140,11 +140,28 @@ struct CpMemo {
     DevBuf x, qkv;  // [tables][Vc][Hc] and [tables][Vc][nqkv] f32
 };
 
+// Decode kernel choice of a weight set (kernels.hpp, TUNE_*): shared by a model and its sessions, set once.
+struct Tuning {
+    std::mutex mu;
+    int mode = TUNE_UNSET;
+    // the choice in force; `want` (TUNE_ALONE / TUNE_SHARED) becomes the choice if none has been made yet
+    int latch(int want) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (mode == TUNE_UNSET) mode = tuning_forced() != TUNE_UNSET ? tuning_forced() : want;
+        return mode;
+    }
+    int peek() {
+        std::lock_guard<std::mutex> lock(mu);
+        return mode;
+    }
+};
+
 struct Model {
     Ctx* ctx = nullptr;
     bool is_view = false;  // a session: weights borrowed from another model, which must outlive it
     std::shared_ptr<SharedLocks> locks = std::make_shared<SharedLocks>();
     std::shared_ptr<CpMemo> cp_memo = std::make_shared<CpMemo>();
+    std::shared_ptr<Tuning> tuning = std::make_shared<Tuning>();
     int dtype = BF16;
     ModelCfg cfg;
     CodecCfg codec;

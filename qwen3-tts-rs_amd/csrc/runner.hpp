@@ -105,8 +105,10 @@ struct Runner {
         return v;
     }
 
+    bool tune_shared;  // decode kernels picked for several streams in flight (the weight set's choice, made once: kernels.hpp)
     Runner(Model& model, Workspace& ws, GemmTimer* t) : m(model), g(ws), timer(t), st(model.ctx->stream), dt(model.dtype), es(dtype_size(model.dtype)) {
         split(true);
+        tune_shared = model.tuning->peek() == TUNE_SHARED;
     }
 
     // split-K factor the consumers of g.part must assume for a GEMM of this shape
@@ -245,7 +247,7 @@ struct Runner {
 
     // finished-output GEMM with epilogue: K walked in phases inside the block at 64-row multiples, whole-K tile otherwise
     void wide_gemm(WMat W, const void* X, int ldx, long x_lo, int M, int N, int K, const FusedEpi& e) {
-        if (gemm_stream_preferred(M, N, K, x_lo != 0)) launch_gemm_stream(st, W, X, ldx, x_lo, M, N, K, e);
+        if (gemm_stream_preferred(M, N, K, x_lo != 0, tune_shared)) launch_gemm_stream(st, W, X, ldx, x_lo, M, N, K, e);
         else launch_gemm_full_k(st, W, X, ldx, x_lo, M, N, K, e);
     }
 
@@ -276,7 +278,7 @@ struct Runner {
         FusedEpi e{};
         e.mode = FUSED_RESID; e.ss_ld = g.ss_ld; e.bias = bias; e.resid = resid ? g.x.as<float>() : nullptr; e.x_out = g.x.as<float>();
         e.xb_out = g.xn.p; e.xb_lo = lo_xn; e.nw = nw; e.ss_out = ss_out;
-        timed(M, N, K, [&] { launch_gemm_k_split(st, W, X, K, x_lo, M, N, K, e); });
+        timed(M, N, K, [&] { launch_gemm_k_split(st, W, X, K, x_lo, M, N, K, e, tune_shared); });
         return fused_resid_tiles(N);
     }
     static bool stack_fusable(const Model& m, const StackW& s) {

@@ -215,15 +215,16 @@ void run_mel(Model& m, const float* audio, const int* n_samples, int B, int max_
 
 // ------------------------------------------------------------------------------------------------
 // run_mel for callers that must not allocate: the staging copies of the clips, of their lengths and of the result live in
-// one fixed device array per GPU instead of buffers grown on demand.  Every call on a GPU shares that GPU's array (calls that
-// overlap on one GPU race); a call overwrites what it reads back, so nothing has to be cleared between calls except
-// the result region, which the call itself zeroes.
+// one fixed device array per GPU instead of buffers grown on demand.  Every call on a GPU shares that GPU's array: calls from
+// any model or session on that GPU take turns (a per-GPU lock held until the result is on the host); a call overwrites what it
+// reads back, so nothing has to be cleared between calls except the result region, which the call itself zeroes.
 constexpr size_t MEL_SCRATCH_BYTES = (size_t)16 << 20;
 static __device__ __align__(256) unsigned char scratch[MEL_SCRATCH_BYTES];
 namespace {
 constexpr int MAX_DEVICES = 64;
 unsigned char* g_scratch_ptr[MAX_DEVICES] = {};  // device address of `scratch` on each GPU (the array's name is only a host-side handle)
 std::mutex g_scratch_mu;
+std::mutex g_scratch_use[MAX_DEVICES];           // held for a whole call: every model and session on a GPU shares that GPU's array
 size_t pad256(size_t n) { return (n + 255) / 256 * 256; }
 }  // namespace
 
@@ -244,8 +245,9 @@ unsigned char* mel_scratch(int device) {
 size_t mel_scratch_bytes() { return MEL_SCRATCH_BYTES; }
 
 void run_mel_noalloc(Model& m, const float* audio, const int* n_samples, int B, int max_samples, float* mel_out, int frames_stride, int* n_frames) {
-    std::lock_guard<std::mutex> lock(m.locks->speaker);  // sessions of one model share these workspaces
     QTTS_CHECK(m.finalized && m.spk_state, ERR_STATE, "model is not finalized");
+    QTTS_CHECK(m.ctx->device >= 0 && m.ctx->device < MAX_DEVICES, ERR_BAD_ARG, "mel scratch: device ordinal out of range");
+    std::lock_guard<std::mutex> use(g_scratch_use[m.ctx->device]);  // the array belongs to the GPU, not to the model
     QTTS_CHECK(B >= 1 && max_samples >= 1 && frames_stride >= 1, ERR_BAD_ARG, "mel: bad batch shape");
     QTTS_HIP(hipSetDevice(m.ctx->device));
     SpeakerState& s = *m.spk_state;

@@ -181,6 +181,45 @@ def test_headline_shape_bf16_logits_beyond_the_first_kv_page():
         m.close()
 
 
+def _gpu_model(shape, dtype):
+    import torch
+    from qwen3_tts_rs_amd import LoaderConfig, Model, synth
+    cfg, ccfg, tmpl = synth.shape_set(shape, "custom_voice")
+    m = Model(cfg, None, LoaderConfig(dtype=dtype))
+    for k, t in synth.iter_weights_torch(synth.talker_keys(cfg), SEED, "cuda:0", dtype == "bf16"):
+        m.load_tensor(k, t)
+    m.finalize()
+    torch.cuda.empty_cache()
+    return m, tmpl
+
+
+def test_kernel_choice_is_fixed_per_weight_set():
+    """The decode kernels of a bf16 model are picked once per weight set - for one stream when its first generate call comes
+    before any session, for several streams when a session is opened first - and the two choices sum in different orders.  A
+    request's codes must therefore not depend on whether a session was opened later, on any model."""
+    m, tmpl = _gpu_model("S17", "bf16")
+    other = None
+    try:
+        frames = 6
+        _, reqs = _batch64(tmpl)
+        first = m.generate(reqs, _greedy(), frames)
+        ses = m.open_session()                       # opened after the first call: the weight set keeps its choice
+        other, _ = _gpu_model("S17", "bf16")
+        ses_other = other.open_session()             # a second weight set, sessions first: the other choice, its own business
+        assert np.array_equal(m.generate(reqs, _greedy(), frames).codes, first.codes)
+        assert np.array_equal(ses.generate(reqs, _greedy(), frames).codes, first.codes)
+        a = other.generate(reqs, _greedy(), frames)
+        b = ses_other.generate(reqs, _greedy(), frames)
+        assert np.array_equal(a.codes, b.codes)
+        assert np.array_equal(m.generate(reqs, _greedy(), frames).codes, first.codes)
+        ses.close()
+        ses_other.close()
+    finally:
+        m.close()
+        if other is not None:
+            other.close()
+
+
 @pytest.mark.parametrize("with_session", [False, True], ids=["one-stream-kernels", "several-streams-kernels"])
 def test_headline_shape_bf16_logits_of_a_batch_of_64(with_session):
     """The benchmarked configuration itself (1.7B-like, bf16, 64 rows): logits of rows 0, 31 and 63 within max-abs 2e-2 of

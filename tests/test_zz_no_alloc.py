@@ -21,6 +21,14 @@ def test_no_alloc_mel_equals_the_allocating_entry_point():
             assert len(ref) == len(got)
             for a, b in zip(ref, got):
                 assert a.shape == b.shape and np.array_equal(a, b)
+        # no device allocation behind the call: the free-memory figure of the device does not move across it
+        import torch
+        m.compute_mel_spectrogram(small, no_alloc=True)
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        m.compute_mel_spectrogram(big, no_alloc=True)
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free0
         # the first call's larger result must not leak into the second call's rows
         again = m.compute_mel_spectrogram(small, no_alloc=True)
         for a, b in zip(m.compute_mel_spectrogram(small), again):

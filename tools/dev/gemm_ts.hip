@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
             FusedEpi e{};
             if (kind == "k_split") {
                 e.mode = FUSED_RESID; e.ss_ld = rows; e.resid = x; e.x_out = x; e.xb_out = xb; e.xb_lo = (long)rows * N; e.nw = nw; e.ss_out = ss;
-                launch_gemm_k_split(st, w, X, K, x_lo, M, N, K, e);
+                launch_gemm_k_split(st, w, X, K, x_lo, M, N, K, e, tuning_forced() == TUNE_SHARED);
 #ifndef HARNESS_FUSED_ONLY
             } else if (kind == "slab") {
                 launch_gemm(st, BF16, w, X, out, M, N, K, gemm_pick_ks(M, N, K, BF16), K, x_lo);

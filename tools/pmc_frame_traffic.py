@@ -6,7 +6,8 @@ traffic of one frame (prefill, weight initialisation and the profiling pass afte
 gfx950 correction: FETCH_SIZE counts a 128-byte request of a 16-byte-per-lane read as 64 bytes, so the read side is doubled;
 WRITE_SIZE is exact for 16-byte-per-lane stores.
 
-    python tools/pmc_frame_traffic.py gpurun_out 12 22 > profiles/r02_frame_traffic.json"""
+    python tools/pmc_frame_traffic.py gpurun_out 12 22 alone > /tmp/alone.json      (then the same for `shared`; the two
+    objects go into bench_data/frame_traffic.json as {"alone": .., "shared": ..}, which bench.py quotes by kernel selection)"""
 import json
 import sys
 
@@ -21,15 +22,16 @@ def load(path):
 
 def main():
     d, f0, f1 = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    tag = sys.argv[4] if len(sys.argv) > 4 else "alone"
     frames = f1 - f0
-    out = {"frames_low": f0, "frames_high": f1, "unit": "bytes per decode frame (single stream, eager launches)",
+    out = {"frames_low": f0, "frames_high": f1, "unit": "bytes per decode frame (single stream, eager launches)", "kernel_selection": tag,
            "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --output-format csv -- python3 bench.py --no-graph --steps 1 --warmup 0 "
                       "--pipeline 1 --no-codec --no-cpu-baseline --frames <N>",
            "correction": "read side = 2 x FETCH_SIZE (gfx950), write side = WRITE_SIZE"}
     per_kernel = {}
     tot = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
-        a, b = load(f"{d}/pmc_frame_{c}_{f0}.sum"), load(f"{d}/pmc_frame_{c}_{f1}.sum")
+        a, b = load(f"{d}/pmc_frame_{tag}_{c}_{f0}.sum"), load(f"{d}/pmc_frame_{tag}_{c}_{f1}.sum")
         scale = 2.0 if c == "FETCH_SIZE" else 1.0
         tot[c] = 0.0
         for k in b:
