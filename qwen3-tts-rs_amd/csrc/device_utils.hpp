@@ -163,6 +163,14 @@ __device__ __forceinline__ int unit_src_piece(int lane, int h2) { return (lane &
 // 16-byte LDS slot (0..127 within the unit's 2 KiB) of piece h of MFMA lane (r, g)
 __device__ __forceinline__ int unit_slot(int r, int g, int h) { return r * 8 + ((2 * g + h) ^ unit_swz(r)); }
 
+// Activations in MFMA fragment order ("packed"): a [64][N] bf16 matrix stored so that the B-operand load of a wave - row tile i,
+// chunk c of 64 columns, half h - is one contiguous KiB: 16-byte piece index ((i N / 64 + c) 2 + h) 64 + lane, lane (r, g) holding
+// columns 64 c + 8 (2 g + h) .. + 7 of row 16 i + r.  Element offset of (row m, column n):
+__device__ __forceinline__ size_t packed_elem(int m, int n, int N) {
+    const int pp = (n & 63) >> 3;
+    return ((((size_t)(m >> 4) * (N >> 6) + (n >> 6)) * 2 + (pp & 1)) * 64 + (m & 15) + 16 * (pp >> 1)) * 8 + (n & 7);
+}
+
 // This lane's fragment of the 16-row weight tile that starts at row n0 (a multiple of 16) of W[N][K]: the piece pair of chunk c
 // (128 bytes of a row) is at p + c * cs and p + c * cs + hs elements - in a row-major matrix, or in one re-laid into fragment
 // order (pk != 0; layout: kernels.hpp WMat).

@@ -543,6 +543,24 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
         }
         g.cp_qkv_in.ensure((size_t)(B + 64) * cp_nqkv * 4);
     }
+    // ---- single-token passes with every GEMM input in MFMA fragment order (k_gemm_frag.hip): no kernel stages its X tile through
+    // LDS, the blocks are small (256 threads, a few KB of LDS) and those of several decode streams share a CU.  QTTS_CP_FRAG=0:
+    // the five-launch layers of k_gemm_fused.hip for these passes too.
+    static const bool frag_off = getenv("QTTS_CP_FRAG") && atoi(getenv("QTTS_CP_FRAG")) == 0;
+    bool use_frag = use_memo && !frag_off && !split_cp && B <= 64 && c.cp.window == 0 && Runner::frag_layer_covered(m.cp) &&
+                    gemm_frag_covers(Vc, Hc, FUSED_PLAIN) && (c.cp.nh * c.cp.d) % 64 == 0 && g.ws.ss_ld >= 64;
+    for (int j = 1; j < G - 1 && use_frag; ++j) use_frag = m.cp_head[(size_t)j].packed;
+    if (use_frag) {
+        auto ensure0 = [&](DevBuf& b, size_t n) {  // rows past the live ones are read by the GEMMs: they must hold finite values
+            if (b.bytes < n) {
+                b.alloc(n);
+                QTTS_HIP(hipMemsetAsync(b.p, 0, n, st));
+            }
+        };
+        ensure0(g.ws.xnp, (size_t)64 * Hc * 2);
+        ensure0(g.ws.attnp, (size_t)64 * c.cp.nh * c.cp.d * 2);
+        ensure0(g.ws.actp, (size_t)64 * c.cp.inter * 2);
+    }
     // ---- single-token passes as ONE launch each (k_cp_pass.hip) where the stack has the shape its work split is written for.
     // Opt-in (QTTS_CP_PASS=1): measured 144 us per pass against 142 us for the five-launch layers on one stream (4.64 ms per frame
     // either way), and 1326 against 1614 audio-s/s with two sessions in flight - its 256 resident workgroups hold half of every
@@ -662,7 +680,18 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
             for (int j = 1; j < G - 1; ++j) {  // code_predictor.rs:480-527
                 // pass input: the embedding row of code j (exact in the model dtype, no remainder plane) -> x, xn, ssA; or, tabulated,
                 // x and the first layer's q|k|v rows as the sampler gathered them
-                if (use_pass) {  // layers + final norm + head of this pass in one launch
+                if (use_frag && !use_pass) {
+                    R.uni_len = j + 2;
+                    for (int l = 0; l < c.cp.layers; ++l)
+                        nt = R.layer_frag(m.cp, l, B, g.cp.kv, l, l + 1 == c.cp.layers ? m.cp.final_norm : m.cp.layers[(size_t)l + 1].ln1, nt,
+                                          l == 0 ? g.cp_qkv_in.as<float>() : nullptr);
+                    R.uni_len = 0;
+                    FusedEpi e{};
+                    e.mode = FUSED_PLAIN; e.ss_in = g.ws.ssA.as<float>(); e.ss_ld = g.ws.ss_ld; e.ntiles_in = nt; e.H_in = Hc; e.eps = c.cp.eps;
+                    e.out_f32 = g.ws.part.as<float>(); e.ld_out = Vc;
+                    R.timed(B, Vc, Hc, [&] { QTTS_CHECK(launch_gemm_frag(st, m.cp_head[(size_t)j], g.ws.xnp.p, Vc, Hc, e), ERR_SHAPE, "generate: head shape"); });
+                    trace_cp(j);
+                } else if (use_pass) {  // layers + final norm + head of this pass in one launch
                     CpPassArgs pa = pass;
                     pa.pos = j + 1; pa.ctx = j + 2;
                     pa.cos = m.cp.cos.as<float>() + (size_t)(j + 1) * (c.cp.d / 2); pa.sin = m.cp.sin.as<float>() + (size_t)(j + 1) * (c.cp.d / 2);

@@ -351,7 +351,8 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KV
         float acc = 0.f;
 #pragma unroll
         for (int q = 0; q < NP; ++q) acc += pa[q][h] * po[q][h][dd];
-        store_split<T>(out + ((long)m * a.nh + (long)g * REP + h) * D + dd, out_lo, acc / pL[h]);
+        if (a.out_packed > 0) out[packed_elem(m, (g * REP + h) * D + dd, a.out_packed)] = from_f32<T>(acc / pL[h]);
+        else store_split<T>(out + ((long)m * a.nh + (long)g * REP + h) * D + dd, out_lo, acc / pL[h]);
     }
     QTTS_TS(6);
 }
@@ -379,6 +380,8 @@ static void launch_attn_decode_rep(hipStream_t st, const QkvPostArgs& a, const K
 void launch_attention_decode(hipStream_t st, int dtype, const QkvPostArgs& a, const KVView& kv, float scale, void* out, long out_lo) {
     QTTS_CHECK(a.d == 64 || a.d == 128, ERR_SHAPE, "attention: head_dim must be 64 or 128");
     QTTS_CHECK(a.M >= 1 && a.nh >= 1 && a.nkv >= 1 && a.nh % a.nkv == 0 && kv.d == a.d && kv.nkv == a.nkv, ERR_SHAPE, "attention: bad shape");
+    QTTS_CHECK(a.out_packed == 0 || (dtype == BF16 && out_lo == 0 && a.M <= 64 && a.out_packed == a.nh * a.d && a.out_packed % 64 == 0), ERR_BAD_ARG,
+               "attention: a fragment-order output needs bf16, one plane, at most 64 tokens and a width of nh * d");
     if (dtype == BF16) {
         if (a.d == 128) launch_attn_decode_rep<bf16_t, 128>(st, a, kv, scale, (bf16_t*)out, out_lo);
         else launch_attn_decode_rep<bf16_t, 64>(st, a, kv, scale, (bf16_t*)out, out_lo);

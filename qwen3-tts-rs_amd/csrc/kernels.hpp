@@ -105,6 +105,13 @@ bool gemm_stream_preferred(int M, int N, int K, bool lo, bool shared);  // it fi
 void launch_gemm_stream(hipStream_t st, WMat W, const void* X, int ldx, long x_lo, int M, int N, int K, const FusedEpi& e);
 void launch_gemm_k_split(hipStream_t st, WMat W, const void* X, int ldx, long x_lo, int M, int N, int K, const FusedEpi& e, bool shared = false);
 
+// ---- k_gemm_frag.hip: 64-row decode GEMM on activations stored in MFMA fragment order ("packed": the 16-byte piece (row tile i,
+// chunk c, half h, lane) of a [64][K] bf16 matrix at piece index ((i K / 64 + c) 2 + h) 64 + lane); no LDS staging of X.  Same
+// epilogue contract as the kernels above, except that activations it writes (xb_out, act) are packed too and always cover 64 rows.
+// false = shape or weight layout not covered.
+bool gemm_frag_covers(int N, int K, int mode);
+bool launch_gemm_frag(hipStream_t st, WMat W, const void* Xp, int N, int K, const FusedEpi& e);
+
 // ---- k_bench.hip (diagnostics)
 void launch_stream(hipStream_t st, const void* src, unsigned* sink, long bytes, int blocks, int pattern, int unroll, int ld_bytes);
 
@@ -181,6 +188,7 @@ struct QkvPostArgs {
     int M, nh, nkv, d, layer;
     float* q_out;        // [Mpad][nh d] f32
     int uni_len = 0;     // decode launches only: > 0 = every token m is Tok{m, uni_len - 1, 0, uni_len}; toks is not read
+    int out_packed = 0;  // decode launches, bf16 only: > 0 = the attention output is a packed [64][out_packed] matrix (device_utils.hpp packed_elem)
 };
 void launch_qkv_post(hipStream_t st, int dtype, const QkvPostArgs& a, const KVView& kv);
 // softmax(q k^T * scale over the token's key range) v  -> out [Mpad][nh d] in dtype

@@ -18,6 +18,8 @@ struct Workspace {
     // fused decode stacks: per-row partial sums of squares of the residual stream, two generations, [tiles][ss_ld]
     DevBuf ssA, ssB;
     long ss_ld = 0;
+    // 64-row decode passes through the fragment-order GEMM (k_gemm_frag.hip): its inputs in MFMA fragment order, 64 rows each
+    DevBuf xnp, attnp, actp;
     // allocates the three GEMM-input buffers for `rows` rows of `wx`, `wq`, `wa` elements (split when `split`)
     void alloc_inputs(size_t rows, size_t wx, size_t wq, size_t wa, size_t es, bool split) {
         const size_t f = split ? 2 : 1;
@@ -324,6 +326,53 @@ struct Runner {
             timed(M, 2 * c.inter, c.hidden, [&] { wide_gemm(w.gate_up_il, g.xn.p, c.hidden, 0, M, 2 * c.inter, c.hidden, e); });
         }
         return k_split_resid(w.down, g.act.p, lo_act, M, c.hidden, c.inter, nullptr, true, next_norm, g.ssA.as<float>());
+    }
+    // The same layer for at most 64 tokens of a decode pass with every GEMM input in MFMA fragment order (k_gemm_frag.hip; g.xnp /
+    // g.attnp / g.actp instead of g.xn / g.attn / g.act): five launches, none of which stages its X tile through LDS.
+    static bool frag_layer_covered(const StackW& s) {
+        const StackCfg& c = s.cfg;
+        const int nq = c.nh * c.d, nqkv = (c.nh + 2 * c.nkv) * c.d;
+        for (const LayerW& w : s.layers)
+            if (!w.qkv.packed || !w.o.packed || !w.gate_up_il.packed || !w.down.packed || w.ls_attn || w.ls_mlp) return false;
+        return gemm_frag_covers(nqkv, c.hidden, FUSED_PLAIN) && gemm_frag_covers(c.hidden, nq, FUSED_RESID) && gemm_frag_covers(2 * c.inter, c.hidden, FUSED_SWIGLU) &&
+               gemm_frag_covers(c.hidden, c.inter, FUSED_RESID);
+    }
+    int layer_frag(const StackW& s, int l, int M, const KVView& kv, int kv_layer, const float* next_norm, int nt_in, const float* qkv_rows = nullptr) {
+        const StackCfg& c = s.cfg;
+        const LayerW& w = s.layers[(size_t)l];
+        const int nq = c.nh * c.d, nqkv = (c.nh + 2 * c.nkv) * c.d;
+        QTTS_CHECK(M <= 64 && uni_len > 0 && g.xnp.p && g.attnp.p && g.actp.p && g.ss_ld >= 64, ERR_STATE, "layer_frag: a decode pass of at most 64 tokens at one position");
+        if (!qkv_rows) {
+            FusedEpi e{};
+            e.mode = FUSED_PLAIN; e.ss_in = g.ssA.as<float>(); e.ss_ld = g.ss_ld; e.ntiles_in = nt_in; e.H_in = c.hidden; e.eps = c.eps;
+            e.bias = w.qkv_bias; e.out_f32 = g.part.as<float>(); e.ld_out = nqkv;
+            timed(M, nqkv, c.hidden, [&] { QTTS_CHECK(launch_gemm_frag(st, w.qkv, g.xnp.p, nqkv, c.hidden, e), ERR_SHAPE, "layer_frag: q|k|v shape"); });
+        }
+        QkvPostArgs qa{};
+        qa.part = qkv_rows ? qkv_rows : g.part.as<float>(); qa.KS = 1; qa.ks_stride = 0; qa.bias = nullptr;
+        qa.q_norm = w.q_norm; qa.k_norm = w.k_norm; qa.eps = c.eps; qa.cos = s.cos.as<float>(); qa.sin = s.sin.as<float>();
+        qa.rope_mode = 0; qa.toks = nullptr; qa.M = M; qa.nh = c.nh; qa.nkv = c.nkv; qa.d = c.d; qa.layer = kv_layer;
+        qa.q_out = g.q.as<float>(); qa.uni_len = uni_len; qa.out_packed = nq;
+        launch_attention_decode(st, dt, qa, kv, (float)std::pow((double)c.d, -0.5), g.attnp.p, 0);
+        {
+            FusedEpi e{};
+            e.mode = FUSED_RESID; e.ss_ld = g.ss_ld; e.bias = w.o_bias; e.resid = g.x.as<float>(); e.x_out = g.x.as<float>();
+            e.xb_out = g.xnp.p; e.nw = w.ln2; e.ss_out = g.ssB.as<float>();
+            timed(M, c.hidden, nq, [&] { QTTS_CHECK(launch_gemm_frag(st, w.o, g.attnp.p, c.hidden, nq, e), ERR_SHAPE, "layer_frag: o shape"); });
+        }
+        {
+            FusedEpi e{};
+            e.mode = FUSED_SWIGLU; e.ss_in = g.ssB.as<float>(); e.ss_ld = g.ss_ld; e.ntiles_in = c.hidden / 16; e.H_in = c.hidden; e.eps = c.eps;
+            e.act = g.actp.p;
+            timed(M, 2 * c.inter, c.hidden, [&] { QTTS_CHECK(launch_gemm_frag(st, w.gate_up_il, g.xnp.p, 2 * c.inter, c.hidden, e), ERR_SHAPE, "layer_frag: gate|up shape"); });
+        }
+        {
+            FusedEpi e{};
+            e.mode = FUSED_RESID; e.ss_ld = g.ss_ld; e.resid = g.x.as<float>(); e.x_out = g.x.as<float>();
+            e.xb_out = g.xnp.p; e.nw = next_norm; e.ss_out = g.ssA.as<float>();
+            timed(M, c.hidden, c.inter, [&] { QTTS_CHECK(launch_gemm_frag(st, w.down, g.actp.p, c.hidden, c.inter, e), ERR_SHAPE, "layer_frag: down shape"); });
+        }
+        return c.hidden / 16;
     }
     // whole stack; afterwards xn = T(x * final_norm) and ssA holds the returned number of tiles
     // qkv_rows0: q|k|v rows of the first layer when they are already there (see layer_fused)

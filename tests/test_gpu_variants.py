@@ -69,7 +69,7 @@ def test_tabulated_pass_starts_change_nothing():
     """The code predictor's tabulated pass starts (projection + first-layer q|k|v per (codebook, code)) hold exactly what the
     launches they replace compute: sampled bf16 codes are the same with the tables switched off."""
     digests = []
-    for env in ({}, {"QTTS_CP_MEMO": "0"}):
+    for env in ({"QTTS_CP_FRAG": "0"}, {"QTTS_CP_FRAG": "0", "QTTS_CP_MEMO": "0"}):   # (the tables feed the five-launch layers here)
         e = dict(os.environ, **env)
         r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + MEMO_SCRIPT], env=e, capture_output=True, text=True, timeout=280)
         assert r.returncode == 0 and "codes " in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
@@ -117,3 +117,51 @@ def test_k_split_row_tiles_change_nothing():
         assert r.returncode == 0 and "codes " in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
         digests.append(r.stdout.split("codes ")[1].split()[0])
     assert digests[0] == digests[1]
+
+
+FRAG_SCRIPT = r"""
+import sys, os
+import numpy as np
+sys.path.insert(0, ROOT)
+from qwen3_tts_rs_amd import GenerationRequest, SamplingConfig, synthetic_model
+m, cfg, ccfg, tmpl = synthetic_model("M0", dtype="bf16", codec=False)
+rng = np.random.default_rng(5)
+reqs = [GenerationRequest(text_ids=rng.integers(10, tmpl["text_hi"], size=6 + 3 * i).astype(np.int32), language="english",
+                          speaker="speaker1", seed=100 + i) for i in range(5)]
+out = m.generate(reqs, SamplingConfig(), 12, trace=True)
+graph = m.generate(reqs, SamplingConfig(), 12)
+assert np.array_equal(graph.codes, out.codes), "graph replay differs from kernel-by-kernel launches"
+np.savez(sys.argv[1], codes=out.codes, cp_logits=out.cp_logits, logits=out.logits)
+m.close()
+print("saved")
+"""
+
+
+def test_fragment_order_code_predictor_passes_agree_with_the_five_launch_layers(tmp_path):
+    """The single-token code-predictor passes through the fragment-order GEMM (the default where its shapes fit) against the same
+    passes through the LDS-tile kernels: the two sum K in different orders, so the code-predictor logits agree to bf16 rounding
+    for as long as the sampled histories agree (five live rows of the 64 the kernels compute)."""
+    import numpy as np
+    res = []
+    for i, env in enumerate(({}, {"QTTS_CP_FRAG": "0"})):
+        path = str(tmp_path / f"r{i}.npz")
+        e = dict(os.environ, **env)
+        r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + FRAG_SCRIPT, path], env=e, capture_output=True, text=True, timeout=280)
+        assert r.returncode == 0 and "saved" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+        res.append(np.load(path))
+    a, b = res
+    checked = 0
+    for row in range(a["codes"].shape[0]):
+        same = (a["codes"][row] == b["codes"][row]).all(axis=1)
+        upto = int(np.argmin(same)) if not same.all() else len(same)
+        for t in range(min(upto + 1, len(same))):
+            agree = a["codes"][row][t][1:] == b["codes"][row][t][1:]
+            if t > 0 and not (a["codes"][row][t - 1] == b["codes"][row][t - 1]).all():
+                break
+            if a["codes"][row][t][0] != b["codes"][row][t][0]:
+                break
+            nj = min((int(np.argmin(agree)) if not agree.all() else len(agree)) + 1, len(agree))
+            err = np.abs(a["cp_logits"][row][t][:nj] - b["cp_logits"][row][t][:nj]).max()
+            assert err <= 2e-2, f"row {row} frame {t}: {err:.4f}"
+            checked += nj
+    assert checked >= 5 * 15     # at least the first frame of every row

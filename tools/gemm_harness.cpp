@@ -51,6 +51,10 @@ int main(int argc, char** argv) {
             if (kind == "k_split") {
                 e.mode = FUSED_RESID; e.ss_ld = rows; e.resid = x; e.x_out = x; e.xb_out = xb; e.xb_lo = (long)rows * N; e.nw = nw; e.ss_out = ss;
                 launch_gemm_k_split(st, w, X, K, x_lo, M, N, K, e, tuning_forced() == TUNE_SHARED);
+            } else if (kind == "frag") {
+                if (mode == 2) { e.mode = FUSED_RESID; e.ss_ld = rows; e.resid = x; e.x_out = x; e.xb_out = xb; e.xb_lo = 0; e.nw = nw; e.ss_out = ss; }
+                else { e.mode = FUSED_PLAIN; e.out_f32 = out; e.ld_out = N; }
+                if (!launch_gemm_frag(st, w, X, N, K, e)) throw Error(ERR_SHAPE, "frag: shape not covered");
 #ifndef HARNESS_FUSED_ONLY
             } else if (kind == "slab") {
                 launch_gemm(st, BF16, w, X, out, M, N, K, gemm_pick_ks(M, N, K, BF16), K, x_lo);
