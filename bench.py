@@ -13,7 +13,10 @@ Every rank holds one full set of weights and decodes its own utterances (no coll
 `--pipeline` batches are in flight at once, each in a decode session with its own HIP stream, and a step is one batch through
 the whole path.  `--mode strong` fixes the total work instead: `--utterances` voice-clone utterances (reference clip -> mel ->
 speaker encoder -> x-vector prompt -> decode -> codec) are dealt to the ranks by shard.assign_utterances, a step is one pass
-over all of them.  Rank 0 prints one JSON line.  The CPU oracle is timed on a bounded sample as a reported baseline (rank 0,
+over all of them.  `--natural-eos` and `--length-spread LO:HI` (utterances of unequal length, in either mode) decode through
+continuous batching (`--continuous` asks for it with fixed lengths too): every session works through its utterances in `--slots` rows, a finished row's slot goes to the next
+queued utterance, and finished utterances are turned into audio in groups of `--codec-group` while the other rows keep
+decoding (`--plain` forces whole batches instead).  Rank 0 prints one JSON line.  The CPU oracle is timed on a bounded sample as a reported baseline (rank 0,
 N = 1 only)."""
 import argparse
 import json
@@ -59,6 +62,19 @@ def parse():
                     help="weak: --batch utterances per GPU per step; strong: --utterances voice-clone utterances in total per step, "
                          "dealt to the ranks")
     ap.add_argument("--utterances", type=int, default=256, help="strong mode: utterances per step over all ranks")
+    ap.add_argument("--continuous", action="store_true",
+                    help="decode through continuous batching (implied by --natural-eos and --length-spread)")
+    ap.add_argument("--plain", action="store_true", help="whole batches through qtts_generate_ex even where continuous batching is implied")
+    ap.add_argument("--length-spread", default=None, metavar="LO:HI",
+                    help="utterance u is LO + hash(u) %% (HI - LO + 1) frames long (EOS suppressed up to its own length) instead of "
+                         "--frames for all: the spread of lengths a real job has")
+    ap.add_argument("--slots", type=int, default=0,
+                    help="continuous batching: rows per session (0 = --batch)")
+    ap.add_argument("--codec-group", type=int, default=32, help="continuous batching: finished utterances per codec decode")
+    ap.add_argument("--queue-order", default="longest-first", choices=["longest-first", "arrival"],
+                    help="continuous batching with --length-spread: a session's queue ordered by the requests' own frame limits, longest "
+                         "first (the rows then drain together at the end of the job instead of idling behind the last long utterance), "
+                         "or left in arrival order")
     ap.add_argument("--dump-codes", default=None, help="rank 0 writes {utterance index: crc32 of its codes} of the last step here (json)")
     return ap.parse_args()
 
@@ -104,13 +120,21 @@ def text_len(u):
     return 8 + (u * 37 + 11) % 57                      # text content length in [8, 64]
 
 
-def make_requests(args, tmpl, rank):
+def own_frames(args, u):
+    """Frame limit of utterance u under --length-spread (0 = the call's --frames)."""
+    if not args.length_spread:
+        return 0
+    lo, hi = (int(v) for v in args.length_spread.split(":"))
+    return lo + (u * 2654435761 % 4294967296) % (hi - lo + 1)
+
+
+def make_requests(args, tmpl, rank, step=0):
     from qwen3_tts_rs_amd import GenerationRequest, synth
     reqs = []
     for b in range(args.batch):
         u = rank * args.batch + b                      # global utterance index
         reqs.append(GenerationRequest(text_ids=synth.synthetic_text_ids(tmpl, text_len(u), u), language="english", speaker="speaker1",
-                                      seed=None if args.greedy else 42 + u))
+                                      seed=None if args.greedy else 42 + u, max_new_tokens=own_frames(args, u + 7919 * step)))
     return reqs
 
 
@@ -243,13 +267,23 @@ def main():
 
     import threading
     from qwen3_tts_rs_amd import SamplingConfig, synth
-    P = max(1, args.pipeline if args.mode == "strong" else min(args.pipeline, args.steps))
+    strong = args.mode == "strong"
+    # fixed-length jobs gain nothing from slot refill (all rows of a batch end together) and a lone last batch decodes faster than
+    # its rows spread over three busy sessions, so whole batches stay the default there
+    continuous = (args.continuous or args.natural_eos or bool(args.length_spread)) and not args.plain
+    if args.length_spread and not continuous:
+        sys.exit("bench.py: --length-spread needs continuous batching (a plain batch runs every row to the same length)")
+    mine = strong_share(args, rank, world) if strong else []
+    if strong:
+        # a rank's share goes through as few sessions as hold it in --batch rows each: a lone stream decodes a frame in about
+        # 60 % of the time each of three concurrent streams takes, with kernels picked for running alone
+        P = max(1, min(args.pipeline, -(-len(mine) // args.batch)))
+    else:
+        P = max(1, min(args.pipeline, args.steps))
     # one set of weights per GPU; every batch in flight beyond the first runs in a session of the same model (its own HIP
     # stream, KV caches, workspaces and frame graph)
     m, cfg, ccfg, tmpl = build_model(args, local)
     models = [m] + [m.open_session() for _ in range(P - 1)]
-    strong = args.mode == "strong"
-    mine = strong_share(args, rank, world) if strong else []
     clips = [reference_clip(u) for u in mine]            # host audio, prepared outside the timed region like the texts
     reqs = make_requests(args, tmpl, rank)
     sampling = SamplingConfig.cli_greedy() if args.greedy else SamplingConfig()
@@ -259,7 +293,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    stats = dict(prefill_ms=0.0, frames_ms=0.0, frames=0, codec_ms=0.0, audio_s=0.0, step_ms=[], first_ms=[], launch_host_ms=0.0, utterances=0)
+    stats = dict(prefill_ms=0.0, frames_ms=0.0, frames=0, codec_ms=0.0, audio_s=0.0, step_ms=[], first_ms=[], launch_host_ms=0.0, utterances=0,
+                 row_frames=0, calls=0)
     out_last = [None]
     lock = threading.Lock()
 
@@ -306,6 +341,57 @@ def main():
                 out_last[0] = out
         return out, wavs
 
+    G = cfg["talker_config"]["num_code_groups"]
+
+    def session_slots(n_queued):
+        if args.slots > 0:
+            return min(args.slots, n_queued)
+        return min(args.batch, n_queued)
+
+    def run_continuous(mod, rq, record, on_codes=None):
+        """One session's utterances through continuous batching; finished utterances go to the codec in groups, on this
+        session's stream, between two frames of its other rows."""
+        t_s = time.perf_counter()
+        pending, tally = [], dict(codec_ms=0.0, audio_s=0.0, done=0)
+
+        def flush():
+            if pending and not args.no_codec:
+                T = max(len(c) for c in pending)
+                arr = np.zeros((len(pending), T, G), np.uint32)
+                for i, c in enumerate(pending):
+                    arr[i, :len(c)] = c
+                mod.decode_codes(arr, [len(c) for c in pending], chunk=-2)
+                tally["codec_ms"] += mod.codec_device_ms()
+            pending.clear()
+
+        def on_done(u, codes, eff):
+            tally["audio_s"] += eff * FRAME_SECONDS
+            tally["done"] += 1
+            if on_codes is not None:
+                on_codes(u, codes[:eff])
+            if eff > 0:
+                pending.append(codes[:eff])
+            if len(pending) >= args.codec_group:
+                flush()
+
+        out = mod.generate(rq, sampling, args.frames, use_graph=not args.no_graph, slots=session_slots(len(rq)), on_done=on_done,
+                           min_new_tokens=0 if args.natural_eos else args.frames)
+        flush()
+        if record:
+            with lock:
+                stats["prefill_ms"] += mod.last_timing["prefill_ms"]
+                stats["frames_ms"] += mod.last_timing["frames_ms"]
+                stats["frames"] += mod.last_timing["frames"]
+                stats["row_frames"] += sum(out.steps_per_utterance)
+                stats["launch_host_ms"] += mod.last_timing["graph_launch_host_ms"]
+                stats["codec_ms"] += tally["codec_ms"]
+                stats["audio_s"] += tally["audio_s"]
+                stats["utterances"] += tally["done"]
+                stats["step_ms"].append((time.perf_counter() - t_s) * 1e3)
+                stats["calls"] += 1
+                out_last[0] = out
+        return out
+
     codes_crc = {}
     probe = [reqs]   # one batch of requests for the eager profiling pass after the timed region
 
@@ -322,9 +408,60 @@ def main():
                                                 speaker_embed=emb[i + j], seed=None if args.greedy else 42 + u) for j, u in enumerate(idx)]))
         return out, zlib.crc32
 
+    def strong_requests():
+        from qwen3_tts_rs_amd import GenerationRequest
+        emb = m.extract_speaker_embedding(clips) if mine else np.zeros((0, 1), np.float32)
+        return [GenerationRequest(text_ids=synth.synthetic_text_ids(tmpl, text_len(u), u), language="english", speaker_embed=emb[j],
+                                  seed=None if args.greedy else 42 + u, max_new_tokens=own_frames(args, u)) for j, u in enumerate(mine)]
+
+    def run_steps_continuous(n_steps, record):
+        """Every session gets one queue per call: in weak mode the batches of all its steps (rows of the next batch start as rows
+        of the previous one finish), in strong mode its part of the rank's share, pass after pass."""
+        import zlib
+        errs = []
+        queues = [[] for _ in range(P)]   # per session: list of (global utterance index or None, request)
+        if strong:
+            for _ in range(n_steps):
+                rq = strong_requests()
+                if rq:
+                    probe[0] = rq[:args.batch]
+                for w in range(P):
+                    queues[w].append([(mine[j], rq[j]) for j in range(w, len(rq), P)])
+        else:
+            for k in range(n_steps):
+                queues[k % P].append([(None, r) for r in (make_requests(args, tmpl, rank, k) if args.length_spread else reqs)])
+            queues = [[sum(q, [])] if q else [] for q in queues]   # one call per session over all its batches
+
+        def worker(w):
+            try:
+                for items in queues[w]:
+                    if not items:
+                        continue
+                    if args.length_spread and args.queue_order == "longest-first":
+                        items = sorted(items, key=lambda it: -(it[1].max_new_tokens or args.frames))
+                    ids = [u for u, _ in items]
+
+                    def keep(i, codes, ids=ids):
+                        if ids[i] is not None and record:
+                            with lock:
+                                codes_crc[ids[i]] = int(zlib.crc32(np.ascontiguousarray(codes).tobytes()))
+                    run_continuous(models[w], [r for _, r in items], record, keep)
+            except Exception as ex:  # surfaced after the join
+                errs.append(ex)
+
+        th = [threading.Thread(target=worker, args=(w,)) for w in range(P)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+
     def run_steps(n_steps, record):
         # weak: steps are dealt round-robin to the in-flight slots; every slot runs its steps back to back on its own stream.
         # strong: every step is one pass over the rank's share, its batches dealt to the slots the same way.
+        if continuous:
+            return run_steps_continuous(n_steps, record)
         errs = []
         if strong:
             work = []
@@ -375,11 +512,17 @@ def main():
     result = None
     if rank == 0:
         es = 2 if args.dtype == "bf16" else 4
-        calls = len(stats["step_ms"])                             # generate calls of this rank in the timed region
-        frames_run = max(stats["frames"] - calls, 1)              # the first frame of each call comes out of the prefill
+        if continuous:
+            frames_run = max(stats["frames"], 1)                  # every frame is a launch; the loop's time includes the admissions
+            rows_live = stats["row_frames"] / frames_run          # mean rows that produced a frame per launch
+            avg_ctx = 40 + stats["row_frames"] / max(stats["utterances"], 1) / 2.0
+        else:
+            calls = len(stats["step_ms"])                         # generate calls of this rank in the timed region
+            frames_run = max(stats["frames"] - calls, 1)          # the first frame of each call comes out of the prefill
+            rows_live = float(args.batch)
+            avg_ctx = 40 + args.frames / 2.0                      # mean prompt (~40 positions) + half the generated frames
         ms_per_frame = stats["frames_ms"] / frames_run            # per stream, HIP events around each call's frame loop
-        avg_ctx = 40 + args.frames / 2.0                          # mean prompt (~40 positions) + half the generated frames
-        bytes_frame = synth.decode_bytes_per_frame(cfg, args.batch, avg_ctx, es)
+        bytes_frame = synth.decode_bytes_per_frame(cfg, rows_live, avg_ctx, es)
         # frame loops of the in-flight batches overlap (and overlap codec decodes): the bandwidth the decode frames achieve
         # together is bounded below by their algorithmic bytes over the whole timed region
         achieved = bytes_frame * frames_run / elapsed / 1e9
@@ -390,7 +533,7 @@ def main():
         # kernels picked for several streams in flight, which is what P > 1 runs), and says where it comes from.
         traffic, traffic_ref = None, None
         tpath = os.path.join(ROOT, "bench_data", "frame_traffic.json")   # a copy lives under profiles/
-        if os.path.exists(tpath) and args.shape == "S17" and args.batch == 64 and args.dtype == "bf16" and not strong:
+        if os.path.exists(tpath) and args.shape == "S17" and args.batch == 64 and args.dtype == "bf16" and not continuous:
             tj = json.load(open(tpath)).get("shared" if P > 1 else "alone")
             if tj:
                 traffic = tj.get("traffic_bytes")
@@ -410,7 +553,7 @@ def main():
                                  "avg_launch_ms": round(ms_per_frame, 4), "streams_sharing_the_gpu": P}}
         # the same frames priced against the matrix cores: at 64 rows a weight-streaming GEMM does 64 FLOP per byte, far below the
         # ridge (~310 FLOP/B), so this is a reported utilisation, not the bound
-        fl_frame = synth.decode_flops_per_frame(cfg, args.batch, avg_ctx)
+        fl_frame = synth.decode_flops_per_frame(cfg, rows_live, avg_ctx)
         mfma_peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
         mfma_ach = fl_frame * frames_run / elapsed / 1e12
         roofline["mfma_utilisation"] = {"achieved": round(mfma_ach, 1), "peak": mfma_peak, "unit": "TFLOP/s",
@@ -434,6 +577,11 @@ def main():
             # one decode of the last batch with nothing else on the GPU: device time of the codec kernels by themselves
             m.decode_output(out_last[0])
             iso_ms = m.codec_device_ms()
+            if continuous:   # the isolated decode takes the first --batch utterances of the last call
+                lo = out_last[0]
+                out_last[0] = type(lo)(codes=lo.codes[:args.batch], num_steps=lo.num_steps, effective_lengths=lo.effective_lengths[:args.batch])
+                m.decode_output(out_last[0])
+                iso_ms = m.codec_device_ms()
             fl = synth.codec_flops_per_frame(ccfg) * sum(out_last[0].effective_lengths)
             peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
             ach = fl / (iso_ms * 1e-3) / 1e12
@@ -462,15 +610,21 @@ def main():
                                     f"(3-10 s reference clips -> mel -> speaker encoder -> x-vector prompts), dealt to the ranks, decoded "
                                     f"in batches of {args.batch}, " if strong else
                                     f"{args.shape} CustomVoice-shaped random-init model, batch {args.batch} synthetic texts per GPU, ") +
-                                   f"{args.frames} frames each ({'greedy' if args.greedy else 'seeded sampling'}, "
+                                   (f"{args.length_spread} frames each by utterance index" if args.length_spread else f"{args.frames} frames each") +
+                                   f" ({'greedy' if args.greedy else 'seeded sampling'}, "
                                    f"{'EOS as sampled' if args.natural_eos else 'EOS suppressed up to that length'}), codec decode "
-                                   f"{'off' if args.no_codec else 'to 24 kHz waveforms on the host'}",
-                       "batch_per_gpu": args.batch, "frames": args.frames, "fixed_length": not args.natural_eos,
+                                   f"{'off' if args.no_codec else 'to 24 kHz waveforms on the host'}" +
+                                   (f"; continuous batching, {stats['calls']} calls, mean {rows_live:.1f} rows live per frame launch, "
+                                    f"finished utterances decoded in groups of {args.codec_group}" +
+                                    (f", queue order {args.queue_order}" if args.length_spread else "") if continuous else ""),
+                       "batch_per_gpu": args.batch, "frames": args.frames, "fixed_length": not (args.natural_eos or args.length_spread),
+                       "continuous_batching": continuous,
                        "utterances_total": args.utterances if strong else args.batch * world,
                        "parallelism": f"dp{world} (per-utterance)"},
             # first audio = the first `first_frames` frames through a streaming decode session (final samples), decoded and on the
             # host while generation continues; full utterance = the reference's own (non-streaming) definition
-            "p50_first_audio_ms": round(float(np.median(stats["first_ms"])), 1), "first_audio_frames": args.first_frames,
+            "p50_first_audio_ms": round(float(np.median(stats["first_ms"])), 1) if stats["first_ms"] else None,
+            "first_audio_frames": args.first_frames if stats["first_ms"] else None,
             "p50_full_utterance_ms": round(float(np.median(stats["step_ms"])), 1), "batches_in_flight": P,
             "phase_ms_per_step": {"prefill": round(stats["prefill_ms"] / args.steps, 2), "frames": round(stats["frames_ms"] / args.steps, 2),
                                   "codec_device": round(stats["codec_ms"] / args.steps, 2)},

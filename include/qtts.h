@@ -100,6 +100,9 @@ typedef struct {
     int non_streaming;             /* GenerationOptions.non_streaming_mode (default 1) */
     int use_seed;                  /* 0: draws come from a time-seeded stream (nn/mt_rng.rs:204-214) */
     uint64_t seed;                 /* MT19937 seed of this utterance's draw stream (nn/mt_rng.rs:196) */
+    int max_new_tokens;            /* qtts_generate_continuous only: this utterance's own frame limit (GenerationOptions.max_new_tokens
+                                    * of a call for it alone); 0 = the call's max_new_tokens, larger values are clamped to it.  The
+                                    * plain batch ignores it: there every row runs to the call's limit, as the reference's batch does. */
 } qtts_request;
 
 /* SamplingConfig (nn/sampling.rs:13-64) as merged by GenerateConfig::merge (model/config.rs:128-157).  The floating
@@ -158,6 +161,12 @@ typedef struct {
      * request owns the stream of its seed, so a row's tokens do not depend on its batch.  Not available with continuous
      * batching (the draw order of a slot schedule has no counterpart in the reference). */
     int shared_rng_stream;
+    /* qtts_generate_continuous only: done_cb(done_user, i, codes [num_steps][groups], num_steps, effective_len) is called on the
+     * calling thread as soon as utterance i has left its row (the values outs[i] receives; codes is valid during the call only).
+     * Between frames the handle's stream is idle, so the callback may run qtts_codec_decode on the same handle - finished
+     * utterances become audio while the other rows keep decoding.  It must not call qtts_generate* on that handle. */
+    void (*done_cb)(void* user, int utterance, const uint32_t* codes, int num_steps, int effective_len);
+    void* done_user;
 } qtts_gen_debug;
 
 /* ConditionalGeneration::generate (nn/generation.rs:815-1194) for n independent utterances decoded as
@@ -168,12 +177,17 @@ int qtts_generate_ex(qtts_model* m, const qtts_request* reqs, int n, const qtts_
                      qtts_codes_out* outs, const qtts_gen_debug* dbg);
 
 /* Continuous batching (no counterpart in the reference, whose batch runs until its last row is done): n utterances are decoded
- * through at most `slots` rows.  A row is retired once it has produced the frame with its EOS or max_new_tokens frames, and its
- * slot is prefilled with the next queued utterance while the other rows keep decoding (rows are polled every 8 frames).  Every
- * utterance gets what a qtts_generate call with that request alone returns: outs[i].num_steps = its own frame count (the EOS
- * frame included, 0 if its first token is EOS), effective_len as there; with a seeded request the draws are the same stream.
- * outs[i].codes holds max_new_tokens * groups u32 as for qtts_generate.  dbg may carry use_graph, profile_gemm and min_new_tokens;
- * traces and the first-chunk hook are not available here. */
+ * through at most `slots` rows.  A row is retired once it has produced the frame with its EOS or its frame limit (the call's
+ * max_new_tokens, or the request's own when it sets one), and its slot is prefilled with the next queued utterance while the
+ * other rows keep decoding (rows are polled every 8 frames).  Every utterance gets the computation a qtts_generate call for it
+ * alone performs: outs[i].num_steps = its own frame count (the EOS frame included, 0 if its first token is EOS), effective_len as
+ * there; with a seeded request the draws are the same stream.  Rows never interact, and admission work (text projection, prompt
+ * prefill) runs through one kernel per GEMM shape whatever the number of prompts admitted together, so an utterance's codes are
+ * bit for bit those of the same request in a qtts_generate batch of the same row count (`slots` rows): the decode kernels are
+ * picked by launch width, and widths of different kernel classes (up to 16, 32, 64, 128 ... rows) sum in different orders, which
+ * in bf16 moves sampled tokens.  In f32 at the shapes of the tests the result equals the batch of one.
+ * outs[i].codes holds max_new_tokens * groups u32 as for qtts_generate.  dbg may carry use_graph, profile_gemm, min_new_tokens and
+ * the done_cb hook; traces and the first-chunk hook are not available here. */
 int qtts_generate_continuous(qtts_model* m, const qtts_request* reqs, int n, const qtts_sampling* s, int max_new_tokens,
                              int slots, qtts_codes_out* outs, const qtts_gen_debug* dbg);
 

@@ -214,6 +214,7 @@ impl HipModel {
                 non_streaming: r.non_streaming_mode as c_int,
                 use_seed: r.seed.is_some() as c_int,
                 seed: r.seed.unwrap_or(0),
+                max_new_tokens: 0,
             })
             .collect();
         let mut bufs: Vec<Vec<u32>> = reqs.iter().map(|_| vec![0u32; max_new_tokens * self.groups]).collect();

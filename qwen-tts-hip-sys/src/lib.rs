@@ -47,6 +47,7 @@ pub struct qtts_request {
     pub non_streaming: c_int,
     pub use_seed: c_int,
     pub seed: u64,
+    pub max_new_tokens: c_int,
 }
 
 #[repr(C)]
@@ -72,6 +73,9 @@ pub struct qtts_codes_out {
 }
 
 pub type qtts_chunk_cb = Option<unsafe extern "C" fn(user: *mut c_void, codes: *const u32, n: c_int, frames: c_int)>;
+pub type qtts_done_cb = Option<
+    unsafe extern "C" fn(user: *mut c_void, utterance: c_int, codes: *const u32, num_steps: c_int, effective_len: c_int),
+>;
 
 #[repr(C)]
 pub struct qtts_gen_debug {
@@ -85,6 +89,8 @@ pub struct qtts_gen_debug {
     pub min_new_tokens: c_int,
     pub cp_logits: *mut c_float,
     pub shared_rng_stream: c_int,
+    pub done_cb: qtts_done_cb,
+    pub done_user: *mut c_void,
 }
 
 extern "C" {

@@ -24,7 +24,8 @@ class Request(C.Structure):
                 ("speaker_embed", C.POINTER(C.c_float)),
                 ("ref_codes", C.POINTER(C.c_uint32)), ("ref_T", C.c_int),
                 ("ref_text_ids", C.POINTER(C.c_uint32)), ("n_ref_text", C.c_int),
-                ("non_streaming", C.c_int), ("use_seed", C.c_int), ("seed", C.c_uint64)]
+                ("non_streaming", C.c_int), ("use_seed", C.c_int), ("seed", C.c_uint64),
+                ("max_new_tokens", C.c_int)]
 
 
 class Sampling(C.Structure):
@@ -39,12 +40,14 @@ class CodesOut(C.Structure):
 
 
 CHUNK_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_int)
+DONE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_uint32), C.c_int, C.c_int)
 
 
 class GenDebug(C.Structure):
     _fields_ = [("logits", C.POINTER(C.c_float)), ("hidden", C.POINTER(C.c_float)), ("use_graph", C.c_int),
                 ("profile_gemm", C.c_int), ("first_frames", C.c_int), ("chunk_cb", CHUNK_CB), ("chunk_user", C.c_void_p),
-                ("min_new_tokens", C.c_int), ("cp_logits", C.POINTER(C.c_float)), ("shared_rng_stream", C.c_int)]
+                ("min_new_tokens", C.c_int), ("cp_logits", C.POINTER(C.c_float)), ("shared_rng_stream", C.c_int),
+                ("done_cb", DONE_CB), ("done_user", C.c_void_p)]
 
 
 EXPORTS = ["qtts_init", "qtts_shutdown", "qtts_last_error", "qtts_stream", "qtts_model_create", "qtts_model_load_tensor",

@@ -75,7 +75,7 @@ struct GenState {
     DevBuf text_rows, extra, trailing, tts_pad_dummy;
     DevBuf ibuf;                             // int scratch: ids / descriptors
     DevBuf toks_prompt, tiles_prompt, toks_dec, toks_cp;
-    DevBuf row_len, step, eos_step, active, hist, uniforms, codes, trailing_len, tts_pad;
+    DevBuf row_len, step, eos_step, active, row_max, hist, uniforms, codes, trailing_len, tts_pad;
     DevBuf trace_logits, trace_hidden, trace_cp;
     StackRun talker, cp;
     size_t cap_rows = 0;
@@ -251,6 +251,13 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
     QTTS_CHECK(!streaming || !shared_rng, ERR_BAD_ARG, "generate: one draw stream for all rows needs the plain batch");
     QTTS_CHECK(!streaming || !(tracing || (dbg && dbg->chunk_cb)), ERR_BAD_ARG, "generate: traces and the first-chunk hook need the plain batch");
 
+    // a request's own frame limit applies to continuous batching only: the plain batch runs every row to the call's limit, as
+    // the reference's batch does
+    auto row_limit_of = [&](int u) {
+        const int own = reqs[u].max_new_tokens;
+        return streaming && own > 0 ? std::min(own, max_new) : max_new;
+    };
+
     // ------------------------------------------------------------------ sizes over every request (the buffers the frame graph
     // points at are allocated once: prompt length and trailing-text length of the longest utterance)
     int Tt_max = 1, max_ctx = 0;
@@ -261,7 +268,7 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
         plan_prompts(c, reqs, ids, rows, all);
         for (int i = 0; i < n; ++i) {
             Tt_max = std::max(Tt_max, all.trail_len[(size_t)i]);
-            max_ctx = std::max(max_ctx, all.row_P[(size_t)i] + max_new);
+            max_ctx = std::max(max_ctx, all.row_P[(size_t)i] + row_limit_of(i));
         }
     }
 
@@ -301,6 +308,7 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
     g.step.ensure((size_t)B * 4);
     g.eos_step.ensure((size_t)B * 4);
     g.active.ensure((size_t)B * 4);
+    g.row_max.ensure((size_t)B * 4);
     g.hist.ensure((size_t)B * V * 4);
     g.uniforms.ensure((size_t)B * max_new * G * 4);
     g.codes.ensure((size_t)B * max_new * G * 4);
@@ -349,7 +357,15 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
     // ------------------------------------------------------------------ admission: requests ids[i] into rows slots[i]
     // (prompt embedding assembly, talker prefill into the row's KV pages, the row's sampling state).  Uses the activation
     // workspace, so it runs between frames; the rows that are decoding keep their state (hidden, KV, histories) untouched.
+    // QTTS_CANONICAL_PREFILL=0: admission GEMMs through the kernels planned for their token count (faster for one or two short
+    // prompts, but a prompt's state then depends on what was admitted with it, in the last bits)
+    static const bool canonical = !(getenv("QTTS_CANONICAL_PREFILL") && atoi(getenv("QTTS_CANONICAL_PREFILL")) == 0);
     auto admit = [&](const std::vector<int>& ids, const std::vector<int>& rws) {
+        struct Canon {
+            Runner& r;
+            Canon(Runner& rr, bool on) : r(rr) { r.canonical_rows = on; }
+            ~Canon() { r.canonical_rows = false; }
+        } canon(R, canonical);
         const int nb = (int)ids.size();
         PromptPlan pl;
         plan_prompts(c, reqs, ids, rws, pl);
@@ -431,6 +447,7 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
                                  (int)pl.icl_rows.size(), G, H, g.extra.as<float>());
         }
         // the rows' sampling state
+        std::vector<int> row_limit((size_t)nb);
         for (int i = 0; i < nb; ++i) {
             const int r = rws[(size_t)i];
             const int one = 1, zero = 0, none = -1;
@@ -439,6 +456,8 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
             QTTS_HIP(hipMemcpyAsync(g.step.as<int>() + r, &zero, 4, hipMemcpyHostToDevice, st));
             QTTS_HIP(hipMemcpyAsync(g.eos_step.as<int>() + r, &none, 4, hipMemcpyHostToDevice, st));
             QTTS_HIP(hipMemcpyAsync(g.active.as<int>() + r, &one, 4, hipMemcpyHostToDevice, st));
+            row_limit[(size_t)i] = row_limit_of(ids[(size_t)i]);
+            QTTS_HIP(hipMemcpyAsync(g.row_max.as<int>() + r, &row_limit[(size_t)i], 4, hipMemcpyHostToDevice, st));
             QTTS_HIP(hipMemsetAsync(g.hist.as<int>() + (size_t)r * V, 0, (size_t)V * 4, st));
             QTTS_HIP(hipMemsetAsync(g.codes.as<unsigned>() + (size_t)r * max_new * G, 0, (size_t)max_new * G * 4, st));
         }
@@ -492,6 +511,24 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
         }
     };
 
+    // development aid: QTTS_DEBUG_SCRUB="<mask>:<byte>" fills workspace buffers with a byte after every admission (bit 0 part,
+    // 1 attn, 2 xn, 3 act, 4 ssA|ssB, 5 q, 6 x rows beyond the batch) - no kernel may depend on what a prefill left behind
+    auto scrub = [&]() {
+        const char* e = getenv("QTTS_DEBUG_SCRUB");
+        if (!e) return;
+        int mask = 0, byte = 0;
+        if (sscanf(e, "%d:%d", &mask, &byte) != 2) return;
+        if (mask & 1) QTTS_HIP(hipMemsetAsync(g.ws.part.p, byte, g.ws.part.bytes, st));
+        if (mask & 2) QTTS_HIP(hipMemsetAsync(g.ws.attn.p, byte, g.ws.attn.bytes, st));
+        if (mask & 4) QTTS_HIP(hipMemsetAsync(g.ws.xn.p, byte, g.ws.xn.bytes, st));
+        if (mask & 8) QTTS_HIP(hipMemsetAsync(g.ws.act.p, byte, g.ws.act.bytes, st));
+        if ((mask & 16) && g.ws.ssA.p) {
+            QTTS_HIP(hipMemsetAsync(g.ws.ssA.p, byte, g.ws.ssA.bytes, st));
+            QTTS_HIP(hipMemsetAsync(g.ws.ssB.p, byte, g.ws.ssB.bytes, st));
+        }
+        if (mask & 32) QTTS_HIP(hipMemsetAsync(g.ws.q.p, byte, g.ws.q.bytes, st));
+        if (mask & 64) QTTS_HIP(hipMemsetAsync(g.ws.x.as<float>() + (size_t)B * Wmax, byte, g.ws.x.bytes - (size_t)B * Wmax * 4, st));
+    };
     // the first B utterances take the rows in order
     int next_req = 0;
     std::vector<int> row_req((size_t)B, -1);
@@ -499,6 +536,7 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
         std::vector<int> ids, rws;
         for (int b = 0; b < B; ++b) { ids.push_back(next_req); rws.push_back(b); row_req[(size_t)b] = next_req++; }
         admit(ids, rws);
+        scrub();
     }
     QTTS_HIP(hipEventRecord(ev1, st));
 
@@ -749,7 +787,7 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
         ea.trailing = g.trailing.as<float>(); ea.trailing_len = g.trailing_len.as<int>(); ea.Tt_max = Tt_max;
         ea.tts_pad = tts_pad_row; ea.G = G; ea.H = H; ea.B = B;
         launch_embed_sum_norm(st, dt, ea, m.talker.layers[0].ln1, c.talker.eps, g.ws.x.as<float>(), g.ws.xn.p, g.ws.lo_xn);
-        launch_advance_step(st, d_step, g.active.as<int>(), g.eos_step.as<int>(), B, max_new, streaming ? 1 : 0);
+        launch_advance_step(st, d_step, g.active.as<int>(), g.eos_step.as<int>(), B, max_new, streaming ? 1 : 0, g.row_max.as<int>());
     };
     auto talker_step = [&]() {  // generation.rs:1002-1026
         launch_make_decode_toks(st, g.row_len.as<int>(), g.toks_dec.as<Tok>(), B, c.talker.window, g.active.as<int>());
@@ -815,6 +853,7 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
     if (streaming) {
         // ---------------------------------------------------------------- continuous batching
         std::vector<uint32_t> hrow((size_t)max_new * G);
+        const auto done_cb = dbg ? dbg->done_cb : nullptr;
         const bool graphed = use_graph && max_new > 1;
         if (graphed) capture(true);
         int live = B, frames = 0;
@@ -835,15 +874,16 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
                 if (e == 0) num_steps = 0;  // ended on its very first token: no frame at all (generation.rs:939,1145-1150)
                 outs[u].num_steps = num_steps;
                 outs[u].effective_len = (e >= 0 && e < num_steps) ? e : num_steps;
-                if (outs[u].codes && num_steps > 0) {
+                if ((outs[u].codes || done_cb) && num_steps > 0)
                     copy_sync(hrow.data(), g.codes.as<unsigned>() + (size_t)b * max_new * G, (size_t)num_steps * G * 4, hipMemcpyDeviceToHost, st);
-                    std::memcpy(outs[u].codes, hrow.data(), (size_t)num_steps * G * 4);
-                }
+                if (outs[u].codes && num_steps > 0) std::memcpy(outs[u].codes, hrow.data(), (size_t)num_steps * G * 4);
+                // the stream is idle here (poll() waited for it), so the callback may run other work of this handle on it
+                if (done_cb) done_cb(dbg->done_user, u, hrow.data(), num_steps, outs[u].effective_len);
                 row_req[(size_t)b] = -1;
                 --live;
                 if (next_req < n) { ids.push_back(next_req); rws.push_back(b); row_req[(size_t)b] = next_req++; ++live; }
             }
-            if (!ids.empty()) admit(ids, rws);
+            if (!ids.empty()) { admit(ids, rws); scrub(); }
         }
         steps_done = frames;
         QTTS_HIP(hipEventRecord(ev2, st));

@@ -400,16 +400,17 @@ void launch_make_decode_toks(hipStream_t st, int* row_len, Tok* toks, int B, int
     hipLaunchKernelGGL(make_decode_toks_kernel, dim3((B + 63) / 64), dim3(64), 0, st, row_len, toks, B, window, active);
 }
 
-__global__ void advance_step_kernel(int* step, int* active, const int* eos_step, int B, int max_steps, int retire) {
+__global__ void advance_step_kernel(int* step, int* active, const int* eos_step, int B, int max_steps, int retire, const int* row_max) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B || active[b] == 0) return;
     const int s = step[b] + 1;
     step[b] = s;
-    if (retire && (s >= max_steps || (eos_step[b] >= 0 && s > eos_step[b]))) active[b] = 0;
+    const int limit = row_max ? min(row_max[b], max_steps) : max_steps;  // a row's own frame limit never exceeds the call's
+    if (retire && (s >= limit || (eos_step[b] >= 0 && s > eos_step[b]))) active[b] = 0;
 }
-void launch_advance_step(hipStream_t st, int* step, int* active, const int* eos_step, int B, int max_steps, int retire) {
+void launch_advance_step(hipStream_t st, int* step, int* active, const int* eos_step, int B, int max_steps, int retire, const int* row_max) {
     QTTS_CHECK(step && active && eos_step && B >= 1 && max_steps >= 1, ERR_BAD_ARG, "advance_step: null argument");
-    hipLaunchKernelGGL(advance_step_kernel, dim3((B + 63) / 64), dim3(64), 0, st, step, active, eos_step, B, max_steps, retire);
+    hipLaunchKernelGGL(advance_step_kernel, dim3((B + 63) / 64), dim3(64), 0, st, step, active, eos_step, B, max_steps, retire, row_max);
 }
 
 }  // namespace qtts

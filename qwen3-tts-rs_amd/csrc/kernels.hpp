@@ -169,7 +169,9 @@ void launch_cast_rows(hipStream_t st, const float* src, void* dst, int ddtype, l
 void launch_make_decode_toks(hipStream_t st, int* row_len, Tok* toks, int B, int window, const int* active);
 // step[b] += 1 for active rows.  retire != 0: a row switches itself off once it has produced max_steps frames or the frame with
 // its first EOS (eos_step[b], -1 = none yet) - what a batch of one would have generated
-void launch_advance_step(hipStream_t st, int* step, int* active, const int* eos_step, int B, int max_steps, int retire);
+// row_max (optional, B ints): each row's own frame limit (the smaller of it and max_steps retires the row)
+void launch_advance_step(hipStream_t st, int* step, int* active, const int* eos_step, int B, int max_steps, int retire,
+                         const int* row_max = nullptr);
 void launch_copy_rows(hipStream_t st, const void* src, const int* sidx, void* dst, const int* didx, int dtype, int n, int H);
 
 // ---- k_attn.hip

@@ -107,6 +107,12 @@ struct Runner {
         return v;
     }
 
+    // Admission work (text projection, prompt prefill) sends every GEMM through the large-M kernel, whatever the token count:
+    // that kernel walks K in one fixed order per output element, so an utterance's prompt state does not depend on how many
+    // other prompts were admitted with it (the split-K plans of the small-M kernels change the summation order with M).
+    bool canonical_rows = false;
+    bool rows_kernel(int M, int N) const { return (M >= rows_kernel_min_m() || canonical_rows) && N % 64 == 0; }
+
     bool tune_shared;  // decode kernels picked for several streams in flight (the weight set's choice, made once: kernels.hpp)
     Runner(Model& model, Workspace& ws, GemmTimer* t) : m(model), g(ws), timer(t), st(model.ctx->stream), dt(model.dtype), es(dtype_size(model.dtype)) {
         split(true);
@@ -115,13 +121,13 @@ struct Runner {
 
     // split-K factor the consumers of g.part must assume for a GEMM of this shape
     int ks_for(int M, int N, int K) const {
-        if (M >= rows_kernel_min_m() && N % 64 == 0) return 1;
+        if (rows_kernel(M, N)) return 1;
         return gemm_pick_ks(M, N, K, dt);
     }
     long kstride(int M, int N) const { return (long)gemm_pad_rows(M) * N; }
 
     void gemm(WMat W, const void* X, int M, int N, int K, int KS, int ldx, long x_lo = 0) {
-        const bool rows = M >= rows_kernel_min_m() && N % 64 == 0;
+        const bool rows = rows_kernel(M, N);
         const bool time = timer && timer->enabled && timer->used + 2 <= 400000;
         if (time) {
             while (timer->ev.size() < timer->used + 2) {

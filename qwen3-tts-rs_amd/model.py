@@ -98,6 +98,7 @@ class GenerationRequest:  # GenerationOptions (nn/generation_options.rs) + text 
     ref_text_ids: Optional[Sequence[int]] = None
     non_streaming_mode: bool = True
     seed: Optional[int] = None
+    max_new_tokens: int = 0      # continuous batching only: this utterance's own frame limit (0 = the call's)
 
 
 @dataclass
@@ -270,11 +271,15 @@ class Model:
     # ------------------------------------------------------------------ generation
     def generate(self, requests: Sequence[GenerationRequest], sampling: SamplingConfig, max_new_tokens: int,
                  trace: bool = False, use_graph: bool = True, profile_gemm: bool = False, first_frames: int = 0,
-                 on_first_chunk=None, min_new_tokens: int = 0, slots: int = 0, shared_rng_stream: bool = False) -> Output:
+                 on_first_chunk=None, min_new_tokens: int = 0, slots: int = 0, shared_rng_stream: bool = False,
+                 on_done=None) -> Output:
         """ConditionalGeneration::generate (nn/generation.rs:815) over a batch of independent utterances.
         slots > 0: continuous batching (qtts_generate_continuous) - the utterances go through at most `slots` rows, a finished
         row's slot is given to the next queued utterance, and every utterance gets the frames a batch of one would produce:
         Output.codes is padded to the longest one, Output.steps_per_utterance holds each one's own count.
+        on_done(i, codes (num_steps, groups), effective_len), continuous batching only, is called as soon as utterance i has left
+        its row; it may call decode_codes on this model (the stream is idle between frames), so finished utterances turn
+        into audio while the other rows keep decoding.
         on_first_chunk(codes (batch, first_frames, groups)) is called once the first `first_frames` frames of every row
         exist, while generation continues afterwards (first-audio hook; the reference has no counterpart).
         min_new_tokens > 0 keeps EOS suppressed for that many frames (fixed-length throughput runs; 0 = the reference's 2).
@@ -317,6 +322,7 @@ class Model:
             reqs[i].non_streaming = int(r.non_streaming_mode)
             reqs[i].use_seed = 0 if r.seed is None else 1
             reqs[i].seed = 0 if r.seed is None else int(r.seed)
+            reqs[i].max_new_tokens = int(r.max_new_tokens or 0)
         codes = np.zeros((n, max_new_tokens, G), np.uint32)
         outs = (_lib.CodesOut * n)()
         for i in range(n):
@@ -347,6 +353,19 @@ class Model:
             keep.append(cb)
             dbg.first_frames = int(first_frames)
             dbg.chunk_cb = cb
+        if on_done is not None:
+            if slots <= 0:
+                raise QttsError(-1, "on_done needs continuous batching (slots > 0)")
+
+            def _done(_user, u, ptr, num_steps, eff):
+                try:  # exceptions must not unwind through the C frames
+                    c = np.ctypeslib.as_array(ptr, shape=(num_steps, G)).copy() if num_steps > 0 else np.zeros((0, G), np.uint32)
+                    on_done(int(u), c, int(eff))
+                except Exception as ex:
+                    cb_err.append(ex)
+            dcb = _lib.DONE_CB(_done)
+            keep.append(dcb)
+            dbg.done_cb = dcb
         if slots > 0:
             if trace or on_first_chunk is not None:
                 raise QttsError(-1, "continuous batching has no traces and no first-chunk hook")

@@ -10,10 +10,10 @@ from conftest import SEED
 pytestmark = pytest.mark.gpu
 
 
-def _model(dtype, eos_gain=6.0):
+def _model(dtype, eos_gain=6.0, shape="T0"):
     import torch
     from qwen3_tts_rs_amd import LoaderConfig, Model, synth
-    cfg, ccfg, tmpl = synth.shape_set("T0", "custom_voice")
+    cfg, ccfg, tmpl = synth.shape_set(shape, "custom_voice")
     eos = cfg["talker_config"]["codec_eos_token_id"]
     m = Model(cfg, None, LoaderConfig(dtype=dtype))
     for k, t in synth.iter_weights_torch(synth.talker_keys(cfg), SEED, "cuda:0", dtype == "bf16"):
@@ -72,4 +72,97 @@ def test_greedy_rows_and_plain_batch_agree_up_to_each_effective_length():
         with pytest.raises(Exception):
             m.generate(reqs, greedy, max_new, slots=3, trace=True)
     finally:
+        m.close()
+
+
+def test_headline_shape_bf16_continuous_rows_equal_plain_batches_of_the_same_width():
+    """The benchmarked shape, dtype and width (1.7B talker, bf16, seeded sampling, 64 rows): 150 utterances through 64 row slots
+    give, for every utterance, bit for bit what a plain 64-row batch holding that utterance gives up to the utterance's own end
+    (same EOS frame, same code ids) - although in the continuous run it was admitted next to rows that were mid-utterance and
+    shared its launches with different neighbours.  (Admission work runs through one kernel per GEMM shape whatever the number
+    of prompts, so a prompt's state does not depend on its admission group; the decode kernels are picked by launch width,
+    which is why the plain batches here are 64 rows wide as well.)"""
+    from qwen3_tts_rs_amd import SamplingConfig
+    m, tmpl = _model("bf16", eos_gain=6.0, shape="S17")
+    try:
+        n, width, max_new = 150, 64, 48
+        reqs = _requests(tmpl, n)
+        sampling = SamplingConfig(temperature=1.0, top_k=0)
+        cont = m.generate(reqs, sampling, max_new, slots=width)
+        ends = cont.effective_lengths
+        assert len(set(ends)) >= 12 and min(ends) < max_new // 4, f"the fixture should end rows at scattered frames, got {ends}"
+        for lo in range(0, n, width):
+            grp = list(range(lo, min(lo + width, n)))
+            own = len(grp)
+            grp += [u % n for u in range(grp[-1] + 1, grp[-1] + 1 + width - own)]   # fillers keep the launch 64 rows wide
+            plain = m.generate([reqs[u] for u in grp], sampling, max_new)
+            for j, u in enumerate(grp[:own]):
+                e = plain.effective_lengths[j]
+                assert cont.effective_lengths[u] == e, f"utterance {u}"
+                assert cont.steps_per_utterance[u] == min(e + 1, max_new), f"utterance {u}"
+                assert np.array_equal(cont.codes[u, :e], plain.codes[j, :e]), f"utterance {u}"
+    finally:
+        m.close()
+
+
+def test_own_frame_limits_and_the_completion_hook():
+    """Every request may carry its own frame limit (continuous batching only), and on_done hands each utterance over the moment
+    it leaves its row: every utterance equals a call for it alone with that limit, the hook fires once per utterance with the
+    codes the call returns, and a codec decode issued from inside the hook (while other rows are mid-utterance) gives the audio
+    a decode after the call gives."""
+    import dataclasses
+    from qwen3_tts_rs_amd import SamplingConfig, synthetic_model
+    m, cfg, ccfg, tmpl = synthetic_model("T0", dtype="f32", codec=True, model_type="custom_voice")
+    try:
+        n, max_new = 11, 36
+        limits = [0 if u % 4 == 3 else 4 + (5 * u) % 29 for u in range(n)]
+        reqs = [dataclasses.replace(r, max_new_tokens=limits[u]) for u, r in enumerate(_requests(tmpl, n))]
+        sampling = SamplingConfig(temperature=1.0, top_k=0)
+        alone = [m.generate([dataclasses.replace(r, max_new_tokens=0)], sampling, limits[u] or max_new, min_new_tokens=max_new)
+                 for u, r in enumerate(reqs)]
+        seen, audio_in_hook = {}, {}
+
+        def on_done(u, codes, eff):
+            assert u not in seen
+            seen[u] = (codes, eff)
+            if len(codes):
+                audio_in_hook[u] = m.decode_codes(codes[None], [len(codes)])[0]
+
+        out = m.generate(reqs, sampling, max_new, slots=3, min_new_tokens=max_new, on_done=on_done)
+        assert sorted(seen) == list(range(n))
+        for u in range(n):
+            want = limits[u] or max_new
+            assert alone[u].num_steps == want
+            assert out.steps_per_utterance[u] == want and out.effective_lengths[u] == want, f"utterance {u}"
+            assert np.array_equal(out.codes[u, :want], alone[u].codes[0]), f"utterance {u}"
+            assert seen[u][1] == want and np.array_equal(seen[u][0], alone[u].codes[0])
+            after = m.decode_codes(alone[u].codes, [want])[0]
+            assert np.array_equal(audio_in_hook[u], after), f"utterance {u}"
+        # the plain batch ignores the per-request limits
+        plain = m.generate(reqs[:3], sampling, 12, min_new_tokens=12)
+        assert plain.num_steps == 12
+        with pytest.raises(Exception):
+            m.generate(reqs, sampling, max_new, on_done=on_done)
+    finally:
+        m.close()
+
+
+def test_decode_does_not_depend_on_what_a_prefill_left_in_the_workspace():
+    """Admissions run between two frames of the rows that are decoding and reuse the activation workspace.  No decode kernel may
+    read what they leave there (rows beyond the batch, split-K slabs, remainder planes, partial sums): a plain batch whose
+    workspace buffers are overwritten after the prefill, one buffer at a time, produces the codes of the undisturbed run."""
+    import os
+    from qwen3_tts_rs_amd import SamplingConfig
+    m, tmpl = _model("bf16", shape="S17")
+    try:
+        reqs = _requests(tmpl, 16)
+        sampling = SamplingConfig(temperature=1.0, top_k=0)
+        base = m.generate(reqs, sampling, 12, min_new_tokens=12)
+        for byte in (0, 0x3c):
+            for bit in range(7):
+                os.environ["QTTS_DEBUG_SCRUB"] = f"{1 << bit}:{byte}"
+                out = m.generate(reqs, sampling, 12, min_new_tokens=12)
+                assert np.array_equal(out.codes, base.codes), f"buffer {bit} filled with {byte:#x}"
+    finally:
+        os.environ.pop("QTTS_DEBUG_SCRUB", None)
         m.close()
