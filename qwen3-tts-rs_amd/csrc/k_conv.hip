@@ -171,6 +171,60 @@ __device__ __forceinline__ void epi_pass(const ConvEpi& e, const float* otile, c
     }
 }
 
+// The same pass with the residual rows already in registers (res[k] = the four values of row k * RPI + r0 the thread read when
+// it built the input tile): nothing is loaded from the residual stream.
+template <typename T, int RT, int GPR, int OP>
+__device__ __forceinline__ void epi_pass_regs(const ConvEpi& e, const float* otile, const int* row_u, const int* row_tp, int n0,
+                                              const float (&res)[RT / (256 / GPR)][4]) {
+    constexpr int RPI = 256 / GPR, IT = RT / RPI;
+    const int c4 = threadIdx.x % GPR, r0 = threadIdx.x / GPR;
+    EpiCols pc;
+    conv_epi_cols<T>(e, n0 + 4 * c4, pc);
+#pragma unroll
+    for (int k = 0; k < IT; ++k) {
+        const int row = k * RPI + r0;
+        const int tp = row_tp[row];
+        if (tp < 0) continue;
+        const long off = conv_epi_offset(e, pc, row_u[row], tp);
+        const float4 a4 = *reinterpret_cast<const float4*>(otile + row * OP + 4 * c4);
+        float v[4] = {a4.x, a4.y, a4.z, a4.w};
+        conv_epi_finish<T>(e, pc, row_u[row], off, v, res[k]);
+    }
+}
+
+// Rows [row0, row0 + RT) of an f32-stream input tile, loaded in the epilogue's thread layout (thread = four channels of every
+// RPI-th row, NP column passes of 4 * GPR channels): the raw values stay in registers as the unit's residual, their SnakeBeta
+// goes into the swizzled bf16 tile.  All loads are issued before the first value is used.
+template <int RT, int GPR, int NP>
+__device__ __forceinline__ void tile_load_snake_keep(uint4* tile, const float* src, int C, int vpr, int row0, const float* sn,
+                                                     float (&res)[NP][RT / (256 / GPR)][4]) {
+    constexpr int RPI = 256 / GPR, IT = RT / RPI;
+    const int c4 = threadIdx.x % GPR, r0 = threadIdx.x / GPR;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int row = row0 + k * RPI + r0, col = p * 4 * GPR + 4 * c4;
+            const float4 x = *reinterpret_cast<const float4*>(src + (long)row * C + col);
+            res[p][k][0] = x.x; res[p][k][1] = x.y; res[p][k][2] = x.z; res[p][k][3] = x.w;
+        }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int col = p * 4 * GPR + 4 * c4;
+        const float4 al = *reinterpret_cast<const float4*>(sn + col), dn = *reinterpret_cast<const float4*>(sn + C + col);
+        const float alv[4] = {al.x, al.y, al.z, al.w}, dnv[4] = {dn.x, dn.y, dn.z, dn.w};
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int row = row0 + k * RPI + r0;
+            u16 h[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) h[q] = f32_to_bf16_bits(snake_apply<bf16_t>(res[p][k][q], alv[q], dnv[q]));
+            char* dst = reinterpret_cast<char*>(tile + row * vpr + ((col / 8) ^ (row & 7))) + (col % 8) * 2;
+            *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+        }
+    }
+}
+
 // The same pass in two halves for kernels that have work to put between the residual loads and their use.
 template <int U>
 struct EpiRows {
@@ -499,7 +553,9 @@ __global__ __launch_bounds__(256, (NT == 3 && sizeof(T) == 2) ? 2 : 1) void conv
     constexpr int CP = 64 * PT, OP = CP + 4, GPR = CP / 4;
     constexpr int EU = (RT / (256 / GPR) >= 8 ? 8 : RT / (256 / GPR));
     // prefetch the first pass's residual rows where that costs no occupancy (at NT = 2 it would take the third block off a CU)
-    constexpr bool ONE_ROUND = RT / (256 / GPR) == EU && sizeof(T) == 2 && NT >= 3;
+    constexpr bool ONE_ROUND = RT / (256 / GPR) == EU && sizeof(T) == 2 && NT >= 3 && !F32IN;
+    // F32IN: the residual rows of the tile, read once when the input tile is built (epilogue thread layout)
+    float res[F32IN ? NT / PT : 1][RT / (256 / GPR)][4];
     __shared__ int row_u[RT], row_tp[RT];
     if ((int)threadIdx.x < RT) {
         const long m = m0 + threadIdx.x;
@@ -522,14 +578,17 @@ __global__ __launch_bounds__(256, (NT == 3 && sizeof(T) == 2) ? 2 : 1) void conv
             sn1[C + c] = dn;
         }
         __syncthreads();
-        tile_load_snake(tile, Xf + m0 * C, C, vpr, rows_t * vpr, sn1);
+        // halo rows as 16-byte slots; the tile's own rows in the epilogue's layout, their raw values kept as the residual
+        const int halo = (taps - 1) * dil;
+        tile_load_snake(tile, Xf + m0 * C, C, vpr, halo * vpr, sn1);
+        tile_load_snake_keep<RT, GPR, NT / PT>(tile, Xf + m0 * C, C, vpr, halo, sn1, res);
     }
     f32x4_t acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    constexpr int PF = MT * NT >= 12 ? 2 : 4;
+    constexpr int PF = (MT * NT >= 12 || F32IN) ? 2 : 4;  // (F32IN: the residual rows take the registers of two stages)
     F a[PF][NT];
     WFragPtr<T> wrow[NT];
 #pragma unroll
@@ -634,9 +693,306 @@ __global__ __launch_bounds__(256, (NT == 3 && sizeof(T) == 2) ? 2 : 1) void conv
             for (int jj = 0; jj < PT; ++jj)
                 *reinterpret_cast<f32x4_t*>(otile + (16 * i + r) * OP + (4 * jj + wave) * 16 + 4 * g) = acc[i][p * PT + jj];
         __syncthreads();
-        if (ONE_ROUND && p == 0) epi_rows_finish<T, RT, GPR, OP>(e, pc0, otile, row_u, R0);
+        if constexpr (F32IN) epi_pass_regs<T, RT, GPR, OP>(e, otile, row_u, row_tp, p * CP, res[p]);
+        else if (ONE_ROUND && p == 0) epi_rows_finish<T, RT, GPR, OP>(e, pc0, otile, row_u, R0);
         else epi_pass<T, RT, GPR, OP>(e, otile, row_u, row_tp, p * CP);
     }
+}
+
+// The fused unit as the vocoder's wide blocks run it - bf16 matrix cores, seven taps, the f32 stream in and out (F32IN above) -
+// as a persistent kernel: a workgroup walks a run of consecutive 64-row tiles.
+//  * The dilation is a template parameter and the K walk is unrolled over its 7 * NT chunks: the LDS addresses of the input rows
+//    are immediates behind one per-lane base, the loop carries no address arithmetic.
+//  * The causal halo of a tile (its first 6 * DIL rows) is the tail of the previous tile's rows, already activated and in LDS:
+//    it is moved down inside LDS, and only the tile's own 64 rows are read from memory - in the epilogue's thread layout, so the
+//    raw values stay in registers as the unit's residual (the stream is read exactly once).
+//  * PREFETCH: the next tile's rows are requested before the current tile's K walk and arrive under it.
+//  * The epilogue is the unit's own (bias, residual, f32 store and / or SnakeBeta of the next layer as one 8-byte store per plane).
+// Instruction issue and exposed memory latency, not the matrix pipe or bandwidth, bound the one-tile-per-workgroup kernel at
+// these widths (about 1900 vector instructions per wave and tile beside 256 matrix instructions, waves parked at s_waitcnt for
+// 46 % of their cycles).
+// Needs e.r == 1, S_in == S_out, ld_out == C, no activation / scale / per-strip bias, resid_f32 = the input stream.
+template <int RT, int GPR, int NP>
+__device__ __forceinline__ void unit_rows_load(const float* src, int C, float (&res)[NP][RT / (256 / GPR)][4]) {
+    constexpr int RPI = 256 / GPR, IT = RT / RPI;
+    const int c4 = threadIdx.x % GPR, r0 = threadIdx.x / GPR;
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const float4 x = *reinterpret_cast<const float4*>(src + (long)(k * RPI + r0) * C + p * 4 * GPR + 4 * c4);
+            res[p][k][0] = x.x; res[p][k][1] = x.y; res[p][k][2] = x.z; res[p][k][3] = x.w;
+        }
+}
+template <int RT, int GPR, int NP>
+__device__ __forceinline__ void unit_rows_store(uint4* tile, int C, int vpr, int row0, const float* sn, const float (&res)[NP][RT / (256 / GPR)][4]) {
+    constexpr int RPI = 256 / GPR, IT = RT / RPI;
+    const int c4 = threadIdx.x % GPR, r0 = threadIdx.x / GPR;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int col = p * 4 * GPR + 4 * c4;
+        const float4 al = *reinterpret_cast<const float4*>(sn + col), dn = *reinterpret_cast<const float4*>(sn + C + col);
+        const float alv[4] = {al.x, al.y, al.z, al.w}, dnv[4] = {dn.x, dn.y, dn.z, dn.w};
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int row = row0 + k * RPI + r0;
+            u16 h[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) h[q] = f32_to_bf16_bits(snake_apply<bf16_t>(res[p][k][q], alv[q], dnv[q]));
+            char* dst = reinterpret_cast<char*>(tile + row * vpr + ((col / 8) ^ (row & 7))) + (col % 8) * 2;
+            *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+        }
+    }
+}
+
+template <int NT, int DIL, int PF, int PT, int BPC, bool PREFETCH>
+__global__ __launch_bounds__(256, BPC) void conv_unit_f32_kernel(const bf16_t* __restrict__ W1, const bf16_t* __restrict__ W2, int wpk,
+                                                                 const float* __restrict__ bias1, const float* __restrict__ alpha2,
+                                                                 const float* __restrict__ den2, int tiles_per_block, ConvEpi e,
+                                                                 const float* __restrict__ Xf, const float* __restrict__ alpha1,
+                                                                 const float* __restrict__ den1) {
+    using T = bf16_t;
+    using F = CFrag<T>;
+    extern __shared__ uint4 tile[];
+    constexpr int MT = 4, RT = 64, C = 64 * NT, TAPS = 7, HALO = (TAPS - 1) * DIL, ROWS_T = RT + HALO;
+    constexpr int vpr = C / 8, cpt = NT, nC = TAPS * cpt, K = TAPS * C;
+    constexpr int CP = 64 * PT, OP = CP + 4, GPR = CP / 4, NP = NT / PT, RPI = 256 / GPR, IT = RT / RPI;
+    static_assert(NT % PT == 0 && HALO < RT, "unit geometry");
+    constexpr int tile_slots = (ROWS_T * vpr * 16 + 1023) / 1024 * 64;  // input tile; behind it the second tile / the f32 staging tile
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const long total = (e.M + RT - 1) / RT;
+    const long t0 = (long)blockIdx.x * tiles_per_block, t1 = t0 + tiles_per_block < total ? t0 + tiles_per_block : total;
+    if (t0 >= total) return;
+    uint4* htile = tile + tile_slots;
+    float* otile = reinterpret_cast<float*>(htile);
+    __shared__ int row_ok[2][RT];
+    __shared__ float sn1[2 * C];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float al = alpha1[c], dn = den1[c];
+        snake_prep<T>(al, dn);
+        sn1[c] = al;
+        sn1[C + c] = dn;
+    }
+    float res[NP][IT][4], resn[PREFETCH ? NP : 1][PREFETCH ? IT : 1][4];
+    unit_rows_load<RT, GPR, NP>(Xf + (t0 * RT + HALO) * C, C, res);
+    __syncthreads();
+    tile_load_snake(tile, Xf + t0 * RT * C, C, vpr, HALO * vpr, sn1);  // the first tile's halo comes from memory
+    const uint4* lrow = tile + r * vpr;  // the lane's row of every 16-row tile; taps and row tiles are constant offsets from it
+    const uint4* hrow = htile + r * vpr;
+    const int c4 = threadIdx.x % GPR, r0 = threadIdx.x / GPR;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    for (long t = t0; t < t1; ++t) {
+        const long m0 = t * RT;
+        // Per-channel parameters and weight addresses are the same for every tile; hoisted out of this loop they would sit in
+        // registers across the K walk and push the kernel into scratch.  Passing the pointers through an empty asm statement
+        // makes them opaque per iteration: every tile re-derives its addresses (a handful of scalar instructions) and re-reads
+        // the parameters from cache where it needs them.
+        const bf16_t *W1l = W1, *W2l = W2;
+        const float *bias1l = bias1, *alpha2l = alpha2, *den2l = den2, *bias2l = e.bias, *alnl = e.alpha_exp, *dnnl = e.beta_den;
+        asm volatile("" : "+s"(W1l), "+s"(W2l), "+s"(bias1l), "+s"(alpha2l), "+s"(den2l), "+s"(bias2l), "+s"(alnl), "+s"(dnnl));
+        WFragPtr<T> wrow[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wrow[j] = WFragPtr<T>(W1l, (4 * j + wave_s) * 16, K, lane, wpk);
+        int* ok = row_ok[t & 1];
+        if ((int)threadIdx.x < RT) {
+            const long m = m0 + threadIdx.x;
+            int v = 0;
+            if (m < e.M) {
+                const long u = m / e.S_in;
+                v = (int)(m - u * e.S_in) < e.lens[u];
+            }
+            ok[threadIdx.x] = v;
+        }
+        if constexpr (!PREFETCH) {
+            if (t > t0) unit_rows_load<RT, GPR, NP>(Xf + (m0 + HALO) * C, C, res);
+        }
+        F a[PF][NT];
+#pragma unroll
+        for (int s = 0; s < PF - 1; ++s)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) a[s][j].load(wrow[j].chunk(s), wrow[j].hs);
+        unit_rows_store<RT, GPR, NP>(tile, C, vpr, HALO, sn1, res);
+        if constexpr (PREFETCH) {
+            if (t + 1 < t1) unit_rows_load<RT, GPR, NP>(Xf + (m0 + RT + HALO) * C, C, resn);
+        }
+        f32x4_t acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < nC; ++q) {
+            if (q + PF - 1 < nC) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) a[(q + PF - 1) % PF][j].load(wrow[j].chunk(q + PF - 1), wrow[j].hs);
+            }
+            const int tap = q / cpt, c = q % cpt;
+            const int x0 = (c * 8 + g * 2) ^ ((r + tap * DIL) & 7);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const uint4* rp = lrow + (16 * i + tap * DIL) * vpr;
+                const uint4 h0 = rp[x0], h1 = rp[x0 ^ 1];
+                F b;
+                __builtin_memcpy(&b, &h0, 16);
+                __builtin_memcpy((char*)&b + 16, &h1, 16);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[q % PF][j], b, acc[i][j]);
+            }
+        }
+        // weights of the 1x1 conv: in flight while the tail of the 7-tap conv is computed
+        constexpr int A2 = cpt < 2 ? cpt : 2;  // (two chunks of them at a time: all NT * NT fragments would not fit beside the rest)
+        F a2[A2][NT];
+        WFragPtr<T> w2row[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) w2row[j] = WFragPtr<T>(W2l, (4 * j + wave_s) * 16, C, lane, wpk);
+#pragma unroll
+        for (int c = 0; c < A2; ++c)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) a2[c][j].load(w2row[j].chunk(c), w2row[j].hs);
+        // tail of the 7-tap conv: bias, SnakeBeta of the bf16 value the unfused layer would have stored, into the second tile
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = (4 * j + wave) * 16 + 4 * g;
+            float bs[4], al[4], dn[4];
+            ld4(bias1l + n, bs);
+            ld4(alpha2l + n, al);
+            ld4(den2l + n, dn);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) snake_prep<T>(al[q], dn[q]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = 16 * i + r;
+                u16 h[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float x = bf16_bits_to_f32(f32_to_bf16_bits(acc[i][j][q] + bs[q]));
+                    h[q] = f32_to_bf16_bits(snake_apply<T>(x, al[q], dn[q]));
+                }
+                char* dst = reinterpret_cast<char*>(htile + row * vpr + ((n / 8) ^ (row & 7))) + (n % 8) * 2;
+                *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+                acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        __syncthreads();  // second tile complete; every wave is past its last read of the input tile
+#pragma unroll
+        for (int c = 0; c < cpt; ++c) {
+            const int x0 = (c * 8 + g * 2) ^ (r & 7);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const uint4* rp = hrow + 16 * i * vpr;
+                const uint4 h0 = rp[x0], h1 = rp[x0 ^ 1];
+                F b;
+                __builtin_memcpy(&b, &h0, 16);
+                __builtin_memcpy((char*)&b + 16, &h1, 16);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a2[c % A2][j], b, acc[i][j]);
+            }
+            if (c + A2 < cpt) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) a2[c % A2][j].load(w2row[j].chunk(c + A2), w2row[j].hs);
+            }
+        }
+        // the next tile's halo: rows [RT, RT + HALO) move to the front (a shift by a multiple of 8 rows keeps the swizzle)
+        if (t + 1 < t1) {
+            for (int sidx = threadIdx.x; sidx < HALO * vpr; sidx += 256) tile[sidx] = tile[RT * vpr + sidx];
+        }
+        __syncthreads();  // every wave is past its reads of the second tile: the f32 staging tile may take its place
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (p > 0) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int jj = 0; jj < PT; ++jj)
+                    *reinterpret_cast<f32x4_t*>(otile + (16 * i + r) * OP + (4 * jj + wave) * 16 + 4 * g) = acc[i][p * PT + jj];
+            __syncthreads();
+            const int col = p * CP + 4 * c4;
+            if (e.Cvalid && col >= e.Cvalid) continue;  // columns past the layer's real width are padding (the barriers are block-uniform)
+            float b2[4], al[4] = {0.f, 0.f, 0.f, 0.f}, dn[4] = {0.f, 0.f, 0.f, 0.f};
+            ld4(bias2l + col, b2);
+            if (e.out2) {
+                ld4(alnl + col, al);
+                ld4(dnnl + col, dn);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) snake_prep<T>(al[q], dn[q]);
+            }
+            const long obase = (m0 + r0 + e.P_out) * C + col;
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+                const int row = k * RPI + r0;
+                if (!ok[row]) continue;
+                const float4 a4 = *reinterpret_cast<const float4*>(otile + row * OP + 4 * c4);
+                const float v[4] = {a4.x + b2[0] + res[p][k][0], a4.y + b2[1] + res[p][k][1], a4.z + b2[2] + res[p][k][2], a4.w + b2[3] + res[p][k][3]};
+                const long off = obase + (long)k * RPI * C;
+                if (e.out_f32) *reinterpret_cast<float4*>(e.out_f32 + off) = make_float4(v[0], v[1], v[2], v[3]);
+                if (e.out2) {
+                    float y[4];
+                    u16 h[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        y[q] = snake_apply<T>(v[q], al[q], dn[q]);
+                        h[q] = f32_to_bf16_bits(y[q]);
+                    }
+                    T* o = (T*)e.out2 + off;
+                    *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+                    if (e.out2_lo) {
+                        u16 l[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) l[q] = f32_to_bf16_bits(y[q] - bf16_bits_to_f32(h[q]));
+                        *reinterpret_cast<uint2*>(o + e.out2_lo) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+                    }
+                }
+            }
+        }
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int k = 0; k < IT; ++k)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) res[p][k][q] = resn[p][k][q];
+        }
+    }
+}
+
+// whether a unit's epilogue is the plain one conv_unit_f32_kernel implements
+static bool unit_f32_epilogue(const ConvEpi& e, int C) {
+    return e.r == 1 && e.S_in == e.S_out && e.ld_out == C && e.Cout == C && e.bias && !e.bias_u && !e.scale && e.act == 0 && !e.resid && e.resid_f32 &&
+           !e.out && !e.out_lo && (e.out_f32 || e.out2) && (!e.out2 || (e.act2 != 1 && e.alpha_exp && e.beta_den)) && e.out2_lo % 4 == 0;
+}
+
+template <int NT, int DIL, int PF, int PT, int BPC, bool PREFETCH>
+static bool launch_unit_f32_cfg(hipStream_t st, const bf16_t* W1, const bf16_t* W2, int wpk, const float* bias1, const float* alpha2, const float* den2,
+                                const ConvEpi& e, const float* Xf, const float* alpha1, const float* den1) {
+    constexpr int RT = 64, C = 64 * NT, HALO = 6 * DIL;
+    constexpr size_t in_b = ((size_t)(RT + HALO) * C * 2 + 1023) / 1024 * 1024;
+    constexpr size_t second = (size_t)RT * C * 2, staging = (size_t)RT * (64 * PT + 4) * 4;
+    constexpr size_t lds = in_b + (second > staging ? second : staging);
+    static_assert(lds * BPC <= (size_t)156 * 1024, "unit tiles of the resident workgroups exceed the LDS of a CU");
+    const long total = (e.M + RT - 1) / RT;
+    if ((long)RT + HALO + 8 > CONV_HALO_SLACK || total > 0x7fffffffL) return false;
+    const long blocks = std::min<long>(total, (long)BPC * 256);
+    const int tpb = (int)((total + blocks - 1) / blocks);
+    const unsigned grid = (unsigned)((total + tpb - 1) / tpb);
+    auto* fn = conv_unit_f32_kernel<NT, DIL, PF, PT, BPC, PREFETCH>;
+    QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_CEILING));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, st, W1, W2, wpk, bias1, alpha2, den2, tpb, e, Xf, alpha1, den1);
+    return true;
+}
+
+// Measured on the vocoder of the benchmark (27 M rows per launch at 128 channels, 9 M at 192; ms per unit, dilations 1 / 3 / 9):
+// 128 channels - general kernel 11.5 / 11.8 / 12.5 (10.5 / 11.2 / 11.7 with the residual kept in registers), this kernel with two
+// workgroups per CU and prefetch 10.4 / 10.9 / 10.7; 192 channels - general 8.4 / 8.3 / 9.1, this kernel (no prefetch: its
+// registers are taken) 8.3 / 7.9 / 7.8.  Skipping one phase at a time shows the phases of a workgroup adding up rather than
+// overlapping (18.7 M rows: 7.3 ms whole, K walk 3.2, tail + 1x1 conv 1.0, row loads 0.8, stores 0.8, the rest 1.4), so what
+// remains is occupancy: LDS and registers hold two such workgroups per CU.
+template <int NT, int DIL>
+static bool launch_unit_f32(hipStream_t st, const bf16_t* W1, const bf16_t* W2, int wpk, const float* bias1, const float* alpha2, const float* den2,
+                            const ConvEpi& e, const float* Xf, const float* alpha1, const float* den1) {
+    if constexpr (NT == 2) return launch_unit_f32_cfg<NT, DIL, 3, 2, 2, true>(st, W1, W2, wpk, bias1, alpha2, den2, e, Xf, alpha1, den1);
+    else return launch_unit_f32_cfg<NT, DIL, 2, 1, 2, false>(st, W1, W2, wpk, bias1, alpha2, den2, e, Xf, alpha1, den1);
 }
 
 bool conv_unit_supported_fwd(int dtype, int C, int taps, int dil);
@@ -659,6 +1015,16 @@ bool launch_unit(hipStream_t st, const T* W1, const T* W2, int wpk, const T* X, 
     const int xcd = conv_xcd_order();
     unsigned grid = 0;
     if (!conv_grid(gx, xcd, grid)) return false;
+    // the kernels that read the f32 stream keep the tile's own rows as the residual: the stream the epilogue names must be that one
+    if (in.Xf && (e.S_in != e.S_out || e.r != 1 || in.Xf != e.resid_f32 + ((long)e.P_out - (long)(taps - 1) * dil) * C)) return false;
+    if constexpr (sizeof(T) == 2 && MT == 4 && (NT == 2 || NT == 3)) {
+        static const bool plain = getenv("QTTS_UNIT_F32") && atoi(getenv("QTTS_UNIT_F32")) == 0;  // 0: the general kernel
+        if (in.Xf && !plain && taps == 7 && (dil == 1 || dil == 3 || dil == 9) && unit_f32_epilogue(e, C) && (const void*)e.resid_f32 != (const void*)e.out_f32) {
+            if (dil == 1) return launch_unit_f32<NT, 1>(st, W1, W2, wpk, bias1, alpha2, den2, e, in.Xf, in.alpha1, in.den1);
+            if (dil == 3) return launch_unit_f32<NT, 3>(st, W1, W2, wpk, bias1, alpha2, den2, e, in.Xf, in.alpha1, in.den1);
+            return launch_unit_f32<NT, 9>(st, W1, W2, wpk, bias1, alpha2, den2, e, in.Xf, in.alpha1, in.den1);
+        }
+    }
     if constexpr (sizeof(T) == 2 && MT == 4) {
         if (in.Xf) {
             auto* fnf = conv_unit_kernel<T, MT, NT, true>;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM-side traffic of one codec decode from the per-kernel counter sums tools/dev/pmc_codec.sh leaves (FETCH_SIZE / WRITE_SIZE in KB).
 
-    python tools/pmc_codec_traffic.py gpurun_out 16 375 > bench_data/r02_codec_traffic.json"""
+    python tools/pmc_codec_traffic.py gpurun_out 16 375 > bench_data/codec_traffic.json"""
 import json
 import sys
 
