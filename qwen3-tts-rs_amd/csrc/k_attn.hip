@@ -357,6 +357,145 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KV
     QTTS_TS(6);
 }
 
+// Decode-step variant for short contexts (the code predictor's passes: every token at one position, at most 16 keys, head_dim
+// 128, bf16, finished q|k|v rows): ONE WAVE per (token, kv head) does what a block of four does above - the token's k, v and REP
+// query heads (RMSNorm, RoPE, KV append), then softmax(q k^T) v over the cached keys plus its own.  Four key groups of 16 lanes
+// take keys gi, gi + 4, gi + 8, gi + 12, so the whole context is one fetch, issued before anything else; the softmax is the plain
+// two-pass one (all scores, maximum, weights), merged across the key groups with the permlane swaps.  No block barrier: a wave
+// passes its own rows from the rotation-pair layout of phase 1 to the eight-dims-per-lane layout of phase 2 through its slice of
+// LDS.  A quarter of the waves and blocks of the general kernel for these launches, which is what counts with several decode
+// streams in flight.
+// Measured on the 1.7B shapes (70 such launches per frame): three sessions in flight +2.3 % audio-s/s; one stream alone 0.12 ms per
+// frame slower than the general kernel (0.04 ms with two waves per pair), so only runs with several streams select it.
+template <int REP>
+__global__ __launch_bounds__(256) void attention_small_kernel(QkvPostArgs a, KVView kv, float scale, bf16_t* out) {
+    using T = bf16_t;
+    constexpr int D = 128, HALF = 64, NK = 4;
+    __shared__ float shm[4][2 + REP][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.x * 4 + wave;
+    if (pair >= a.M * a.nkv) return;
+    float (*sh)[D] = shm[wave];
+    const int m = pair / a.nkv, g = pair - m * a.nkv;
+    const int ctx = a.uni_len, pos = ctx - 1;
+    const int gi = lane >> 4, li = lane & 15;
+    const int ncol = (a.nh + 2 * a.nkv) * D;
+    // the cached keys and values (a lane group's own key slot is patched in from LDS later; slots past the context are masked)
+    float kf[NK][8], vf[NK][8];
+#pragma unroll
+    for (int n = 0; n < NK; ++n) {
+        const int key = n * 4 + gi;
+        const int p = key < pos ? key : 0;
+        load8(kv_ptr<T>(kv, a.layer, m, p, 0, g) + li * 8, kf[n]);
+        load8(kv_ptr<T>(kv, a.layer, m, p, 1, g) + li * 8, vf[n]);
+    }
+    // ---- phase 1: lane = rotation pair (i, i + 64) of k, v and the REP query heads
+    const float* prow = a.part + (long)m * ncol;
+    float x1[2 + REP], x2[2 + REP];
+#pragma unroll
+    for (int hh = 0; hh < 2 + REP; ++hh) {
+        const int head = hh == 0 ? a.nh + g : (hh == 1 ? a.nh + a.nkv + g : g * REP + (hh - 2));
+        x1[hh] = prow[head * D + lane];
+        x2[hh] = prow[head * D + lane + HALF];
+    }
+    const float cs = a.cos[(long)pos * HALF + lane], sn = a.sin[(long)pos * HALF + lane];
+    const float kw1 = a.k_norm ? a.k_norm[lane] : 1.f, kw2 = a.k_norm ? a.k_norm[lane + HALF] : 1.f;
+    const float qw1 = a.q_norm ? a.q_norm[lane] : 1.f, qw2 = a.q_norm ? a.q_norm[lane + HALF] : 1.f;
+#pragma unroll
+    for (int hh = 0; hh < 2 + REP; ++hh) {
+        float y1 = x1[hh], y2 = x2[hh];
+        if (hh != 1) {
+            if (hh == 0 ? a.k_norm != nullptr : a.q_norm != nullptr) {
+                const float ss = wave_sum(y1 * y1 + y2 * y2);
+                const float mm = sqrtf(ss / (float)D + a.eps);
+                y1 = y1 / mm * (hh == 0 ? kw1 : qw1);
+                y2 = y2 / mm * (hh == 0 ? kw2 : qw2);
+            }
+            const float r1 = y1 * cs - y2 * sn, r2 = y1 * sn + y2 * cs;
+            y1 = r1;
+            y2 = r2;
+        }
+        if (hh < 2) {
+            T* dst = kv_ptr<T>(kv, a.layer, m, pos, hh, g);
+            const T b1 = from_f32<T>(y1), b2 = from_f32<T>(y2);
+            dst[lane] = b1;
+            dst[lane + HALF] = b2;
+            y1 = to_f32<T>(b1);  // the value later passes will read back from the cache
+            y2 = to_f32<T>(b2);
+        }
+        sh[hh][lane] = y1;
+        sh[hh][lane + HALF] = y2;
+    }
+    // the wave's own LDS writes, then its reads in the other layout: LDS serves one wave's accesses in order
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // ---- phase 2: lane = dims li * 8 .. + 7 of the keys of group gi
+    float qv[REP][8], ko[8], vo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ko[e] = sh[0][li * 8 + e]; vo[e] = sh[1][li * 8 + e]; }
+#pragma unroll
+    for (int h = 0; h < REP; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[h][e] = sh[2 + h][li * 8 + e];
+    float sc[NK][REP], mx[REP];
+#pragma unroll
+    for (int h = 0; h < REP; ++h) mx[h] = -INFINITY;
+#pragma unroll
+    for (int n = 0; n < NK; ++n) {
+        const int key = n * 4 + gi;
+        const bool own = key == pos, valid = key < ctx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            kf[n][e] = own ? ko[e] : kf[n][e];
+            vf[n][e] = valid ? (own ? vo[e] : vf[n][e]) : 0.f;  // a padding slot's row is whatever the cache holds: keep inf / NaN out
+        }
+#pragma unroll
+        for (int h = 0; h < REP; ++h) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += qv[h][e] * kf[n][e];
+            s = row16_sum(s);
+            sc[n][h] = valid ? s * scale : -INFINITY;
+            mx[h] = fmaxf(mx[h], sc[n][h]);
+        }
+    }
+    const auto fmx = [](float x, float y) { return fmaxf(x, y); };
+    const auto add = [](float x, float y) { return x + y; };
+#pragma unroll
+    for (int h = 0; h < REP; ++h) {
+        mx[h] = fold_rows(fold_halves(mx[h], fmx), fmx);  // key 0 is always valid: the maximum is finite
+        float l = 0.f, o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int n = 0; n < NK; ++n) {
+            const float p = expf(sc[n][h] - mx[h]);
+            l += p;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += p * vf[n][e];
+        }
+        l = fold_rows(fold_halves(l, add), add);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fold_rows(fold_halves(o[e], add), add);
+        if (gi == 0) {
+            const float inv = 1.0f / l;
+            u16 hb[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hb[e] = f32_to_bf16_bits(o[e] * inv);
+            const int col = (g * REP + h) * D + li * 8;
+            T* dst = a.out_packed > 0 ? out + packed_elem(m, col, a.out_packed) : out + (long)m * a.nh * D + col;
+            *reinterpret_cast<uint4*>(dst) = make_uint4((unsigned)hb[0] | ((unsigned)hb[1] << 16), (unsigned)hb[2] | ((unsigned)hb[3] << 16),
+                                                        (unsigned)hb[4] | ((unsigned)hb[5] << 16), (unsigned)hb[6] | ((unsigned)hb[7] << 16));
+        }
+    }
+}
+
+// QTTS_ATTN_SMALL=0: short-context decode launches through the general kernel
+static bool attn_small_enabled() {
+    static const bool on = !(getenv("QTTS_ATTN_SMALL") && atoi(getenv("QTTS_ATTN_SMALL")) == 0);
+    return on;
+}
+
 template <typename T, int D, int NG>
 static void launch_attn_decode_ng(hipStream_t st, const QkvPostArgs& a, const KVView& kv, float scale, T* out, long out_lo) {
     const int rep = a.nh / kv.nkv;
@@ -382,6 +521,13 @@ void launch_attention_decode(hipStream_t st, int dtype, const QkvPostArgs& a, co
     QTTS_CHECK(a.M >= 1 && a.nh >= 1 && a.nkv >= 1 && a.nh % a.nkv == 0 && kv.d == a.d && kv.nkv == a.nkv, ERR_SHAPE, "attention: bad shape");
     QTTS_CHECK(a.out_packed == 0 || (dtype == BF16 && out_lo == 0 && a.M <= 64 && a.out_packed == a.nh * a.d && a.out_packed % 64 == 0), ERR_BAD_ARG,
                "attention: a fragment-order output needs bf16, one plane, at most 64 tokens and a width of nh * d");
+    if (dtype == BF16 && a.d == 128 && a.small && a.uni_len >= 1 && a.uni_len <= 16 && a.KS == 1 && !a.bias && out_lo == 0 && attn_small_enabled() &&
+        (a.nh == kv.nkv || a.nh == 2 * kv.nkv)) {
+        const dim3 grid((unsigned)((a.M * kv.nkv + 3) / 4));
+        if (a.nh == kv.nkv) hipLaunchKernelGGL(attention_small_kernel<1>, grid, dim3(256), 0, st, a, kv, scale, (bf16_t*)out);
+        else hipLaunchKernelGGL(attention_small_kernel<2>, grid, dim3(256), 0, st, a, kv, scale, (bf16_t*)out);
+        return;
+    }
     if (dtype == BF16) {
         if (a.d == 128) launch_attn_decode_rep<bf16_t, 128>(st, a, kv, scale, (bf16_t*)out, out_lo);
         else launch_attn_decode_rep<bf16_t, 64>(st, a, kv, scale, (bf16_t*)out, out_lo);

@@ -180,7 +180,7 @@ struct Runner {
         qa.part = g.part.as<float>(); qa.KS = ks; qa.ks_stride = kstride(M, nqkv); qa.bias = fk ? nullptr : w.qkv_bias;
         qa.q_norm = w.q_norm; qa.k_norm = w.k_norm; qa.eps = c.eps; qa.cos = s.cos.as<float>(); qa.sin = s.sin.as<float>();
         qa.rope_mode = 0; qa.toks = toks; qa.M = M; qa.nh = c.nh; qa.nkv = c.nkv; qa.d = c.d; qa.layer = kv_layer;
-        qa.q_out = g.q.as<float>(); qa.uni_len = decode ? uni_len : 0;
+        qa.q_out = g.q.as<float>(); qa.uni_len = decode ? uni_len : 0; qa.small = tune_shared ? 1 : 0;
         if (decode) {
             launch_attention_decode(st, dt, qa, kv, (float)std::pow((double)c.d, -0.5), g.attn.p, lo_attn);
         } else {
@@ -316,7 +316,7 @@ struct Runner {
         qa.part = qkv_rows ? qkv_rows : g.part.as<float>(); qa.KS = 1; qa.ks_stride = 0; qa.bias = nullptr;
         qa.q_norm = w.q_norm; qa.k_norm = w.k_norm; qa.eps = c.eps; qa.cos = s.cos.as<float>(); qa.sin = s.sin.as<float>();
         qa.rope_mode = 0; qa.toks = toks; qa.M = M; qa.nh = c.nh; qa.nkv = c.nkv; qa.d = c.d; qa.layer = kv_layer;
-        qa.q_out = g.q.as<float>(); qa.uni_len = decode ? uni_len : 0;
+        qa.q_out = g.q.as<float>(); qa.uni_len = decode ? uni_len : 0; qa.small = tune_shared ? 1 : 0;
         const float scale = (float)std::pow((double)c.d, -0.5);
         if (decode) {
             launch_attention_decode(st, dt, qa, kv, scale, g.attn.p, lo_attn);
@@ -358,7 +358,7 @@ struct Runner {
         qa.part = qkv_rows ? qkv_rows : g.part.as<float>(); qa.KS = 1; qa.ks_stride = 0; qa.bias = nullptr;
         qa.q_norm = w.q_norm; qa.k_norm = w.k_norm; qa.eps = c.eps; qa.cos = s.cos.as<float>(); qa.sin = s.sin.as<float>();
         qa.rope_mode = 0; qa.toks = nullptr; qa.M = M; qa.nh = c.nh; qa.nkv = c.nkv; qa.d = c.d; qa.layer = kv_layer;
-        qa.q_out = g.q.as<float>(); qa.uni_len = uni_len; qa.out_packed = nq;
+        qa.q_out = g.q.as<float>(); qa.uni_len = uni_len; qa.out_packed = nq; qa.small = tune_shared ? 1 : 0;
         launch_attention_decode(st, dt, qa, kv, (float)std::pow((double)c.d, -0.5), g.attnp.p, 0);
         {
             FusedEpi e{};

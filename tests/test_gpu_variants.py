@@ -165,3 +165,36 @@ def test_fragment_order_code_predictor_passes_agree_with_the_five_launch_layers(
             assert err <= 2e-2, f"row {row} frame {t}: {err:.4f}"
             checked += nj
     assert checked >= 5 * 15     # at least the first frame of every row
+
+
+def _cp_logits_agree(a, b, rows_needed):
+    import numpy as np
+    checked = 0
+    for row in range(a["codes"].shape[0]):
+        for t in range(a["codes"].shape[1]):
+            if t > 0 and not (a["codes"][row][t - 1] == b["codes"][row][t - 1]).all():
+                break
+            if a["codes"][row][t][0] != b["codes"][row][t][0]:
+                break
+            agree = a["codes"][row][t][1:] == b["codes"][row][t][1:]
+            nj = min((int(np.argmin(agree)) if not agree.all() else len(agree)) + 1, len(agree))
+            err = np.abs(a["cp_logits"][row][t][:nj] - b["cp_logits"][row][t][:nj]).max()
+            assert err <= 2e-2, f"row {row} frame {t}: {err:.4f}"
+            checked += nj
+    assert checked >= rows_needed * 15
+
+
+def test_one_wave_short_context_attention_agrees_with_the_general_kernel(tmp_path):
+    """With several decode streams in flight the code predictor's passes (at most 16 keys) run their attention with one wave per
+    (token, kv head) instead of a block of four: same arithmetic up to the softmax's summation order, so the code-predictor logits
+    agree to bf16 rounding for as long as the sampled histories agree.  Both runs use the kernel selection of shared mode."""
+    import numpy as np
+    res = []
+    for i, env in enumerate(({"QTTS_TUNE": "shared"}, {"QTTS_TUNE": "shared", "QTTS_ATTN_SMALL": "0"})):
+        path = str(tmp_path / f"s{i}.npz")
+        r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + FRAG_SCRIPT, path], env=dict(os.environ, **env), capture_output=True,
+                           text=True, timeout=280)
+        assert r.returncode == 0 and "saved" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+        res.append(np.load(path))
+    assert not np.array_equal(res[0]["cp_logits"], res[1]["cp_logits"]), "the switch selected the same kernel twice"
+    _cp_logits_agree(res[0], res[1], 5)
