@@ -74,7 +74,7 @@ void qtts_model_free(qtts_model* m);
  * and streaming decode, mel, speaker embedding, audio encoding, timing, info) accepts it and runs on the session's stream;
  * qtts_model_load_tensor* and qtts_model_finalize fail on it.  Sessions of one model may be driven from different host
  * threads (one thread per session); the codec decoder's buffers belong to the handle too (codec decodes of several sessions run
- * side by side; up to QTTS_CODEC_SCRATCH_MB, default 48 GiB, each), while the speaker encoder and the codec encoder keep one set
+ * side by side; up to QTTS_CODEC_SCRATCH_MB, default 24 GiB, each), while the speaker encoder and the codec encoder keep one set
  * of workspaces per model, so calls into each of them are serialised across sessions.  Close every session before
  * qtts_model_free of the model it was opened on. */
 typedef qtts_model qtts_session;

@@ -786,8 +786,10 @@ void run_codec_decode(Model& m, const uint32_t* codes, const int* lens, int B, i
     std::stable_sort(pieces.begin(), pieces.end(), [](const Piece& a, const Piece& b) { return a.len > b.len; });
     w.codes.ensure((size_t)B * T_max * s.Q * 4);
     copy_sync(w.codes.p, codes, (size_t)B * T_max * s.Q * 4, hipMemcpyHostToDevice, m.ctx->stream);
-    // ---- groups bounded by a scratch budget
-    static const size_t budget = (size_t)(getenv("QTTS_CODEC_SCRATCH_MB") ? std::max(64, atoi(getenv("QTTS_CODEC_SCRATCH_MB"))) : 49152) << 20;
+    // ---- groups bounded by a scratch budget.  The vocoder's widest stage holds, per 12.5 Hz frame of an utterance, 1920 rows x 128
+    // channels of two f32 streams plus the bf16 copies in front of it: about 3.6 MB per utterance-frame at the reference-default
+    // shapes.  24 GiB per handle (18 utterances of 375 frames per group) costs 1 % of the decode's time against 48 GiB; 12 GiB 3.5 %.
+    static const size_t budget = (size_t)(getenv("QTTS_CODEC_SCRATCH_MB") ? std::max(64, atoi(getenv("QTTS_CODEC_SCRATCH_MB"))) : 24576) << 20;
     Decoder dec(m);
     size_t i = 0;
     while (i < pieces.size()) {
