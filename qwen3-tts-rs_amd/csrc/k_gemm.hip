@@ -433,7 +433,14 @@ static void launch_rows_t(hipStream_t st, const T* W, int wpk, const T* X, float
 #define QTTS_ROWS(nt, nch)                                                                                                          \
     hipLaunchKernelGGL((gemm_rows_kernel<T, nt, nch, EPI, LO>), dim3(N / (64 * nt), gy), dim3(256), 0, st, W, X, o, N, K, ldx, cpt, \
                        tap_stride, base, e, x_lo, wpk)
-        if (N % 128 == 0) {
+        // QTTS_ROWS_WIDE=0: two column tiles per wave for every shape
+        static const bool wide = !(getenv("QTTS_ROWS_WIDE") && atoi(getenv("QTTS_ROWS_WIDE")) == 0);
+        if (wide && !EPI && LO && N % 256 == 0 && nC % 2 == 0) {
+            // two activation planes: with two column tiles per wave the LDS reads of the X fragments take as long as the MFMAs they
+            // feed; four column tiles per wave halve them (64 x 256 block tiles; the 1.7B talker's prefill: 32.3 -> 27.5 ms).  The
+            // choice depends on the layer, never on the row count.
+            QTTS_ROWS(4, 2);
+        } else if (N % 128 == 0) {
             if (nC % 4 == 0) QTTS_ROWS(2, 4);
             else if (nC % 3 == 0) QTTS_ROWS(2, 3);
             else if (nC % 2 == 0) QTTS_ROWS(2, 2);
