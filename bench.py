@@ -62,6 +62,9 @@ def parse():
                     help="weak: --batch utterances per GPU per step; strong: --utterances voice-clone utterances in total per step, "
                          "dealt to the ranks")
     ap.add_argument("--utterances", type=int, default=256, help="strong mode: utterances per step over all ranks")
+    ap.add_argument("--strong-rows", type=int, default=0,
+                    help="strong mode: rows per decode launch (0 = by the rank's share: 128 from 256 utterances on, else 64 - on one MI355X "
+                         "two sessions of 128 rows decode 2255 audio-s/s, three of 64 2049, two of 64 1667, one of 128 1467)")
     ap.add_argument("--continuous", action="store_true",
                     help="decode through continuous batching (implied by --natural-eos and --length-spread)")
     ap.add_argument("--plain", action="store_true", help="whole batches through qtts_generate_ex even where continuous batching is implied")
@@ -275,8 +278,10 @@ def main():
         sys.exit("bench.py: --length-spread needs continuous batching (a plain batch runs every row to the same length)")
     mine = strong_share(args, rank, world) if strong else []
     if strong:
-        # a rank's share goes through as few sessions as hold it in --batch rows each: a lone stream decodes a frame in about
-        # 60 % of the time each of three concurrent streams takes, with kernels picked for running alone
+        # the job is a fixed set of utterances, so the rows per launch are the scheduler's choice (the weak line keeps the named
+        # batch of 64); a rank's share goes through as few sessions as hold it: a lone stream decodes a frame in about 60 % of
+        # the time each of three concurrent streams takes, with kernels picked for running alone
+        args.batch = args.strong_rows if args.strong_rows > 0 else (128 if len(mine) >= 256 else 64)
         P = max(1, min(args.pipeline, -(-len(mine) // args.batch)))
     else:
         P = max(1, min(args.pipeline, args.steps))
