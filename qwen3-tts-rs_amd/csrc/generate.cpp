@@ -585,8 +585,8 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
     // LDS, the blocks are small (256 threads, a few KB of LDS) and those of several decode streams share a CU.  QTTS_CP_FRAG=0:
     // the five-launch layers of k_gemm_fused.hip for these passes too.
     static const bool frag_off = getenv("QTTS_CP_FRAG") && atoi(getenv("QTTS_CP_FRAG")) == 0;
-    bool use_frag = use_memo && !frag_off && !split_cp && B <= 64 && c.cp.window == 0 && Runner::frag_layer_covered(m.cp) &&
-                    gemm_frag_covers(Vc, Hc, FUSED_PLAIN) && (c.cp.nh * c.cp.d) % 64 == 0 && g.ws.ss_ld >= 64;
+    bool use_frag = use_memo && !frag_off && !split_cp && B <= 128 && c.cp.window == 0 && Runner::frag_layer_covered(m.cp) &&
+                    gemm_frag_covers(Vc, Hc, FUSED_PLAIN) && (c.cp.nh * c.cp.d) % 64 == 0 && g.ws.ss_ld >= (B <= 64 ? 64 : 128);
     for (int j = 1; j < G - 1 && use_frag; ++j) use_frag = m.cp_head[(size_t)j].packed;
     if (use_frag) {
         auto ensure0 = [&](DevBuf& b, size_t n) {  // rows past the live ones are read by the GEMMs: they must hold finite values
@@ -595,9 +595,9 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
                 QTTS_HIP(hipMemsetAsync(b.p, 0, n, st));
             }
         };
-        ensure0(g.ws.xnp, (size_t)64 * Hc * 2);
-        ensure0(g.ws.attnp, (size_t)64 * c.cp.nh * c.cp.d * 2);
-        ensure0(g.ws.actp, (size_t)64 * c.cp.inter * 2);
+        ensure0(g.ws.xnp, (size_t)128 * Hc * 2);
+        ensure0(g.ws.attnp, (size_t)128 * c.cp.nh * c.cp.d * 2);
+        ensure0(g.ws.actp, (size_t)128 * c.cp.inter * 2);
     }
     // ---- single-token passes as ONE launch each (k_cp_pass.hip) where the stack has the shape its work split is written for.
     // Opt-in (QTTS_CP_PASS=1): measured 144 us per pass against 142 us for the five-launch layers on one stream (4.64 ms per frame
@@ -727,7 +727,7 @@ static void generate_impl(Model& m, const qtts_request* reqs, int n, const qtts_
                     FusedEpi e{};
                     e.mode = FUSED_PLAIN; e.ss_in = g.ws.ssA.as<float>(); e.ss_ld = g.ws.ss_ld; e.ntiles_in = nt; e.H_in = Hc; e.eps = c.cp.eps;
                     e.out_f32 = g.ws.part.as<float>(); e.ld_out = Vc;
-                    R.timed(B, Vc, Hc, [&] { QTTS_CHECK(launch_gemm_frag(st, m.cp_head[(size_t)j], g.ws.xnp.p, Vc, Hc, e), ERR_SHAPE, "generate: head shape"); });
+                    R.timed(B, Vc, Hc, [&] { QTTS_CHECK(launch_gemm_frag(st, m.cp_head[(size_t)j], g.ws.xnp.p, Vc, Hc, e, B <= 64 ? 64 : 128), ERR_SHAPE, "generate: head shape"); });
                     trace_cp(j);
                 } else if (use_pass) {  // layers + final norm + head of this pass in one launch
                     CpPassArgs pa = pass;

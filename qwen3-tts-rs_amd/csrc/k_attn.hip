@@ -519,8 +519,8 @@ static void launch_attn_decode_rep(hipStream_t st, const QkvPostArgs& a, const K
 void launch_attention_decode(hipStream_t st, int dtype, const QkvPostArgs& a, const KVView& kv, float scale, void* out, long out_lo) {
     QTTS_CHECK(a.d == 64 || a.d == 128, ERR_SHAPE, "attention: head_dim must be 64 or 128");
     QTTS_CHECK(a.M >= 1 && a.nh >= 1 && a.nkv >= 1 && a.nh % a.nkv == 0 && kv.d == a.d && kv.nkv == a.nkv, ERR_SHAPE, "attention: bad shape");
-    QTTS_CHECK(a.out_packed == 0 || (dtype == BF16 && out_lo == 0 && a.M <= 64 && a.out_packed == a.nh * a.d && a.out_packed % 64 == 0), ERR_BAD_ARG,
-               "attention: a fragment-order output needs bf16, one plane, at most 64 tokens and a width of nh * d");
+    QTTS_CHECK(a.out_packed == 0 || (dtype == BF16 && out_lo == 0 && a.M <= 128 && a.out_packed == a.nh * a.d && a.out_packed % 64 == 0), ERR_BAD_ARG,
+               "attention: a fragment-order output needs bf16, one plane, at most 128 tokens and a width of nh * d");
     if (dtype == BF16 && a.d == 128 && a.small && a.uni_len >= 1 && a.uni_len <= 16 && a.KS == 1 && !a.bias && out_lo == 0 && attn_small_enabled() &&
         (a.nh == kv.nkv || a.nh == 2 * kv.nkv)) {
         const dim3 grid((unsigned)((a.M * kv.nkv + 3) / 4));

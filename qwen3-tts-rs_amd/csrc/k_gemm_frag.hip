@@ -144,8 +144,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_frag_kernel(const bf16_t* __rest
 }
 
 template <int NTB, int MTB, int CPW, int NW = 4>
-void launch_frag_mode(hipStream_t st, const bf16_t* W, const bf16_t* Xp, int N, int K, const FusedEpi& e) {
-    dim3 grid(N / (16 * NTB), 4 / MTB);
+void launch_frag_mode(hipStream_t st, const bf16_t* W, const bf16_t* Xp, int N, int K, const FusedEpi& e, int rows) {
+    dim3 grid(N / (16 * NTB), rows / 16 / MTB);
     if (e.mode == FUSED_PLAIN) hipLaunchKernelGGL((gemm_frag_kernel<NTB, MTB, CPW, FUSED_PLAIN, NW>), grid, dim3(64 * NW), 0, st, W, Xp, N, K, e);
     else if (e.mode == FUSED_SWIGLU) hipLaunchKernelGGL((gemm_frag_kernel<NTB, MTB, CPW, FUSED_SWIGLU, NW>), grid, dim3(64 * NW), 0, st, W, Xp, N, K, e);
     else hipLaunchKernelGGL((gemm_frag_kernel<NTB, MTB, CPW, FUSED_RESID, NW>), grid, dim3(64 * NW), 0, st, W, Xp, N, K, e);
@@ -160,29 +160,29 @@ bool gemm_frag_covers(int N, int K, int mode) {
     return cpw == 4 || cpw == 8;
 }
 
-// 64 rows; W fragment order [N][K]; Xp packed [64][K].  16 x 16 output tiles per block for N <= 2048 and for RESID (N = hidden, long K),
-// 32 x 32 otherwise.
-bool launch_gemm_frag(hipStream_t st, WMat Wm, const void* Xp, int N, int K, const FusedEpi& e) {
-    if (!Wm.packed || !gemm_frag_covers(N, K, e.mode)) return false;
+// rows = 64 or 128; W fragment order [N][K]; Xp packed [rows][K].  16 x 16 output tiles per block for N <= 2048 and for RESID (N = hidden,
+// long K), 32 x 32 otherwise.
+bool launch_gemm_frag(hipStream_t st, WMat Wm, const void* Xp, int N, int K, const FusedEpi& e, int rows) {
+    if (!Wm.packed || !gemm_frag_covers(N, K, e.mode) || (rows != 64 && rows != 128)) return false;
     QTTS_CHECK(e.mode != FUSED_PLAIN || (e.out_f32 && e.ld_out >= N), ERR_BAD_ARG, "gemm_frag: missing output");
     QTTS_CHECK(e.mode != FUSED_SWIGLU || e.act, ERR_BAD_ARG, "gemm_frag: missing activation output");
-    QTTS_CHECK(e.mode != FUSED_RESID || (e.x_out && e.xb_out && e.nw && e.ss_out && e.ss_ld >= 64), ERR_BAD_ARG, "gemm_frag: missing residual outputs");
-    QTTS_CHECK(!e.ss_in || (e.ntiles_in >= 1 && e.H_in >= 1 && e.ss_ld >= 64), ERR_BAD_ARG, "gemm_frag: bad norm partials");
+    QTTS_CHECK(e.mode != FUSED_RESID || (e.x_out && e.xb_out && e.nw && e.ss_out && e.ss_ld >= rows), ERR_BAD_ARG, "gemm_frag: missing residual outputs");
+    QTTS_CHECK(!e.ss_in || (e.ntiles_in >= 1 && e.H_in >= 1 && e.ss_ld >= rows), ERR_BAD_ARG, "gemm_frag: bad norm partials");
     const bf16_t* w = (const bf16_t*)Wm.p;
     const bf16_t* x = (const bf16_t*)Xp;
     const int cpw = K / 64 / 4;
     static const int nw8 = getenv("QTTS_FRAG_WAVES") ? atoi(getenv("QTTS_FRAG_WAVES")) == 8 : 0;
     if (e.mode == FUSED_RESID || N <= 2048) {
-        if (nw8 && cpw == 8) launch_frag_mode<1, 1, 4, 8>(st, w, x, N, K, e);
-        else if (nw8 && cpw == 12) launch_frag_mode<1, 1, 6, 8>(st, w, x, N, K, e);
-        else if (cpw == 8) launch_frag_mode<1, 1, 8>(st, w, x, N, K, e);
-        else if (cpw == 12) launch_frag_mode<1, 1, 12>(st, w, x, N, K, e);
-        else if (cpw == 4) launch_frag_mode<1, 1, 4>(st, w, x, N, K, e);
-        else if (cpw == 2) launch_frag_mode<1, 1, 2>(st, w, x, N, K, e);
+        if (nw8 && cpw == 8) launch_frag_mode<1, 1, 4, 8>(st, w, x, N, K, e, rows);
+        else if (nw8 && cpw == 12) launch_frag_mode<1, 1, 6, 8>(st, w, x, N, K, e, rows);
+        else if (cpw == 8) launch_frag_mode<1, 1, 8>(st, w, x, N, K, e, rows);
+        else if (cpw == 12) launch_frag_mode<1, 1, 12>(st, w, x, N, K, e, rows);
+        else if (cpw == 4) launch_frag_mode<1, 1, 4>(st, w, x, N, K, e, rows);
+        else if (cpw == 2) launch_frag_mode<1, 1, 2>(st, w, x, N, K, e, rows);
         else return false;
     } else {
-        if (cpw == 4) launch_frag_mode<2, 2, 4>(st, w, x, N, K, e);
-        else if (cpw == 8) launch_frag_mode<2, 2, 8>(st, w, x, N, K, e);
+        if (cpw == 4) launch_frag_mode<2, 2, 4>(st, w, x, N, K, e, rows);
+        else if (cpw == 8) launch_frag_mode<2, 2, 8>(st, w, x, N, K, e, rows);
         else return false;
     }
     return true;

@@ -110,7 +110,7 @@ void launch_gemm_k_split(hipStream_t st, WMat W, const void* X, int ldx, long x_
 // epilogue contract as the kernels above, except that activations it writes (xb_out, act) are packed too and always cover 64 rows.
 // false = shape or weight layout not covered.
 bool gemm_frag_covers(int N, int K, int mode);
-bool launch_gemm_frag(hipStream_t st, WMat W, const void* Xp, int N, int K, const FusedEpi& e);
+bool launch_gemm_frag(hipStream_t st, WMat W, const void* Xp, int N, int K, const FusedEpi& e, int rows = 64);  // rows: 64 or 128 (packed rows of Xp)
 
 // ---- k_bench.hip (diagnostics)
 void launch_stream(hipStream_t st, const void* src, unsigned* sink, long bytes, int blocks, int pattern, int unroll, int ld_bytes);

@@ -333,7 +333,7 @@ struct Runner {
         }
         return k_split_resid(w.down, g.act.p, lo_act, M, c.hidden, c.inter, nullptr, true, next_norm, g.ssA.as<float>());
     }
-    // The same layer for at most 64 tokens of a decode pass with every GEMM input in MFMA fragment order (k_gemm_frag.hip; g.xnp /
+    // The same layer for at most 128 tokens of a decode pass with every GEMM input in MFMA fragment order (k_gemm_frag.hip; g.xnp /
     // g.attnp / g.actp instead of g.xn / g.attn / g.act): five launches, none of which stages its X tile through LDS.
     static bool frag_layer_covered(const StackW& s) {
         const StackCfg& c = s.cfg;
@@ -347,12 +347,13 @@ struct Runner {
         const StackCfg& c = s.cfg;
         const LayerW& w = s.layers[(size_t)l];
         const int nq = c.nh * c.d, nqkv = (c.nh + 2 * c.nkv) * c.d;
-        QTTS_CHECK(M <= 64 && uni_len > 0 && g.xnp.p && g.attnp.p && g.actp.p && g.ss_ld >= 64, ERR_STATE, "layer_frag: a decode pass of at most 64 tokens at one position");
+        const int prow = M <= 64 ? 64 : 128;  // packed rows of the fragment-order buffers
+        QTTS_CHECK(M <= 128 && uni_len > 0 && g.xnp.p && g.attnp.p && g.actp.p && g.ss_ld >= prow, ERR_STATE, "layer_frag: a decode pass of at most 128 tokens at one position");
         if (!qkv_rows) {
             FusedEpi e{};
             e.mode = FUSED_PLAIN; e.ss_in = g.ssA.as<float>(); e.ss_ld = g.ss_ld; e.ntiles_in = nt_in; e.H_in = c.hidden; e.eps = c.eps;
             e.bias = w.qkv_bias; e.out_f32 = g.part.as<float>(); e.ld_out = nqkv;
-            timed(M, nqkv, c.hidden, [&] { QTTS_CHECK(launch_gemm_frag(st, w.qkv, g.xnp.p, nqkv, c.hidden, e), ERR_SHAPE, "layer_frag: q|k|v shape"); });
+            timed(M, nqkv, c.hidden, [&] { QTTS_CHECK(launch_gemm_frag(st, w.qkv, g.xnp.p, nqkv, c.hidden, e, prow), ERR_SHAPE, "layer_frag: q|k|v shape"); });
         }
         QkvPostArgs qa{};
         qa.part = qkv_rows ? qkv_rows : g.part.as<float>(); qa.KS = 1; qa.ks_stride = 0; qa.bias = nullptr;
@@ -364,19 +365,19 @@ struct Runner {
             FusedEpi e{};
             e.mode = FUSED_RESID; e.ss_ld = g.ss_ld; e.bias = w.o_bias; e.resid = g.x.as<float>(); e.x_out = g.x.as<float>();
             e.xb_out = g.xnp.p; e.nw = w.ln2; e.ss_out = g.ssB.as<float>();
-            timed(M, c.hidden, nq, [&] { QTTS_CHECK(launch_gemm_frag(st, w.o, g.attnp.p, c.hidden, nq, e), ERR_SHAPE, "layer_frag: o shape"); });
+            timed(M, c.hidden, nq, [&] { QTTS_CHECK(launch_gemm_frag(st, w.o, g.attnp.p, c.hidden, nq, e, prow), ERR_SHAPE, "layer_frag: o shape"); });
         }
         {
             FusedEpi e{};
             e.mode = FUSED_SWIGLU; e.ss_in = g.ssB.as<float>(); e.ss_ld = g.ss_ld; e.ntiles_in = c.hidden / 16; e.H_in = c.hidden; e.eps = c.eps;
             e.act = g.actp.p;
-            timed(M, 2 * c.inter, c.hidden, [&] { QTTS_CHECK(launch_gemm_frag(st, w.gate_up_il, g.xnp.p, 2 * c.inter, c.hidden, e), ERR_SHAPE, "layer_frag: gate|up shape"); });
+            timed(M, 2 * c.inter, c.hidden, [&] { QTTS_CHECK(launch_gemm_frag(st, w.gate_up_il, g.xnp.p, 2 * c.inter, c.hidden, e, prow), ERR_SHAPE, "layer_frag: gate|up shape"); });
         }
         {
             FusedEpi e{};
             e.mode = FUSED_RESID; e.ss_ld = g.ss_ld; e.resid = g.x.as<float>(); e.x_out = g.x.as<float>();
             e.xb_out = g.xnp.p; e.nw = next_norm; e.ss_out = g.ssA.as<float>();
-            timed(M, c.hidden, c.inter, [&] { QTTS_CHECK(launch_gemm_frag(st, w.down, g.actp.p, c.hidden, c.inter, e), ERR_SHAPE, "layer_frag: down shape"); });
+            timed(M, c.hidden, c.inter, [&] { QTTS_CHECK(launch_gemm_frag(st, w.down, g.actp.p, c.hidden, c.inter, e, prow), ERR_SHAPE, "layer_frag: down shape"); });
         }
         return c.hidden / 16;
     }

@@ -126,8 +126,8 @@ sys.path.insert(0, ROOT)
 from qwen3_tts_rs_amd import GenerationRequest, SamplingConfig, synthetic_model
 m, cfg, ccfg, tmpl = synthetic_model("M0", dtype="bf16", codec=False)
 rng = np.random.default_rng(5)
-reqs = [GenerationRequest(text_ids=rng.integers(10, tmpl["text_hi"], size=6 + 3 * i).astype(np.int32), language="english",
-                          speaker="speaker1", seed=100 + i) for i in range(5)]
+reqs = [GenerationRequest(text_ids=rng.integers(10, tmpl["text_hi"], size=6 + 3 * (i % 7)).astype(np.int32), language="english",
+                          speaker="speaker1", seed=100 + i) for i in range(int(os.environ.get("FRAG_ROWS", "5")))]
 out = m.generate(reqs, SamplingConfig(), 12, trace=True)
 graph = m.generate(reqs, SamplingConfig(), 12)
 assert np.array_equal(graph.codes, out.codes), "graph replay differs from kernel-by-kernel launches"
@@ -198,3 +198,17 @@ def test_one_wave_short_context_attention_agrees_with_the_general_kernel(tmp_pat
         res.append(np.load(path))
     assert not np.array_equal(res[0]["cp_logits"], res[1]["cp_logits"]), "the switch selected the same kernel twice"
     _cp_logits_agree(res[0], res[1], 5)
+
+
+def test_fragment_order_passes_at_more_than_64_rows(tmp_path):
+    """70 rows: the fragment-order GEMMs then run on 128 packed rows (eight row tiles instead of four); same check as at 5 rows."""
+    import numpy as np
+    res = []
+    for i, env in enumerate(({"FRAG_ROWS": "70"}, {"FRAG_ROWS": "70", "QTTS_CP_FRAG": "0"})):
+        path = str(tmp_path / f"w{i}.npz")
+        r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + FRAG_SCRIPT, path], env=dict(os.environ, **env), capture_output=True,
+                           text=True, timeout=280)
+        assert r.returncode == 0 and "saved" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+        res.append(np.load(path))
+    assert not np.array_equal(res[0]["cp_logits"], res[1]["cp_logits"]), "the switch selected the same kernels twice"
+    _cp_logits_agree(res[0], res[1], 70)
