@@ -281,7 +281,10 @@ def main():
         # the job is a fixed set of utterances, so the rows per launch are the scheduler's choice (the weak line keeps the named
         # batch of 64); a rank's share goes through as few sessions as hold it: a lone stream decodes a frame in about 60 % of
         # the time each of three concurrent streams takes, with kernels picked for running alone
-        args.batch = args.strong_rows if args.strong_rows > 0 else (128 if len(mine) >= 256 else 64)
+        if args.strong_rows > 0:
+            args.batch = args.strong_rows
+        elif args.batch == 64:   # (an explicit --batch is kept)
+            args.batch = 128 if len(mine) >= 256 else 64
         P = max(1, min(args.pipeline, -(-len(mine) // args.batch)))
     else:
         P = max(1, min(args.pipeline, args.steps))
