@@ -91,8 +91,13 @@ class Oracle:
         c = dict(t["code_predictor_config"])
         lt = c.get("layer_types")
         c["sliding_window_effective"] = -1  # default layer types are all full_attention (code_predictor_config.rs:172-186)
-        if lt and any(x == "sliding_attention" for x in lt):
-            raise NotImplementedError("per-layer sliding code-predictor attention")
+        sliding = bool(lt and any(x == "sliding_attention" for x in lt)) or (
+            bool(c.get("use_sliding_window", False)) and int(c.get("max_window_layers", 28)) < int(c.get("num_hidden_layers", 5)))
+        win = c.get("sliding_window", 4096)
+        # the code predictor's context never exceeds num_code_groups + 1 positions: a window at least that long cuts nothing
+        # (nn/attention/standard.rs:28-39 with the default window of code_predictor_config.rs:135-137)
+        if sliding and win and int(win) < int(t["num_code_groups"]) + 1:
+            raise NotImplementedError("per-layer sliding code-predictor attention with a window shorter than its context")
         misc = np.array([t["vocab_size"], t["text_hidden_size"], t["text_vocab_size"], t["num_code_groups"],
                          c["vocab_size"], t["codec_eos_token_id"], t["codec_bos_id"], t["codec_pad_id"],
                          t["codec_think_id"], t["codec_nothink_id"], t["codec_think_bos_id"], t["codec_think_eos_id"],

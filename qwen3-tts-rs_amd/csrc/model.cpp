@@ -35,15 +35,22 @@ void Model::parse_config(const std::string& config_json, const char* codec_json)
     const Json& c = t.at("code_predictor_config");
     cfg.cp = stack_from(c, 5, 3072, 8);
     cfg.cp.window = 0;
-    if (c.has("layer_types"))
-        for (auto& e : c.at("layer_types").arr)
-            QTTS_CHECK(e.str != "sliding_attention", ERR_BAD_ARG, "per-layer sliding attention in the code predictor is not supported");
-    if (c.bool_or("use_sliding_window", false) && c.int_or("max_window_layers", 28) < cfg.cp.layers)
-        throw Error(ERR_BAD_ARG, "per-layer sliding attention in the code predictor is not supported");
     cfg.vocab = t.int_or("vocab_size", 3072);
     cfg.text_hidden = t.int_or("text_hidden_size", 2048);
     cfg.text_vocab = t.int_or("text_vocab_size", 151936);
     cfg.groups = t.int_or("num_code_groups", 32);
+    {
+        // Layers of the code predictor may be typed "sliding_attention" (nn/attention/standard.rs:28-39; layer types as
+        // code_predictor_config.rs:172-186 derives them).  Its context never exceeds num_code_groups + 1 positions, so a window at
+        // least that long (the default is 4096, code_predictor_config.rs:135-137) cuts nothing and the layer is a full-attention
+        // layer; a shorter window on some layers only would need a per-layer key range, which is not built.
+        bool sliding = c.bool_or("use_sliding_window", false) && c.int_or("max_window_layers", 28) < cfg.cp.layers;
+        if (c.has("layer_types"))
+            for (auto& e : c.at("layer_types").arr) sliding = sliding || e.str == "sliding_attention";
+        const int win = c.has("sliding_window") ? c.int_or("sliding_window", 0) : 4096;  // null: no window
+        QTTS_CHECK(!sliding || win <= 0 || win >= cfg.groups + 1, ERR_BAD_ARG,
+                   "per-layer sliding attention in the code predictor with a window shorter than its context is not supported");
+    }
     cfg.cp_vocab = c.int_or("vocab_size", 2048);
     cfg.eos = t.int_or("codec_eos_token_id", 4198);
     cfg.bos = t.int_or("codec_bos_id", 4197);

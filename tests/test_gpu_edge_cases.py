@@ -3,6 +3,8 @@ attention, attention biases, top-p sampling, disabled repetition penalty, mixed 
 runs.  fp32, token-exact against the CPU oracle."""
 import copy
 
+import json
+
 import numpy as np
 import pytest
 
@@ -73,6 +75,35 @@ def test_sliding_window_talker(bind):
             assert not np.array_equal(ref.codes, out.codes)       # the window really changes the result
         finally:
             m2.close()
+    finally:
+        m.close()
+
+
+def test_code_predictor_layers_typed_sliding_attention(bind):
+    """`layer_types` may mark code-predictor layers "sliding_attention" (nn/attention/standard.rs:28-39).  The code predictor never
+    sees more than num_code_groups + 1 positions, so with the default window (4096) such a layer is a full-attention layer: same
+    tokens as without the marking, against the oracle too.  A window shorter than the context is refused with a clear message."""
+    from qwen3_tts_rs_amd import LoaderConfig, Model, QttsError, synth
+
+    def mut(cfg):
+        cp = cfg["talker_config"]["code_predictor_config"]
+        cp["layer_types"] = ["full_attention" if i % 2 else "sliding_attention" for i in range(cp["num_hidden_layers"])]
+        cp["sliding_window"] = 4096
+
+    m, o, cfg, tmpl = _pair(bind, mut)
+    try:
+        texts = [synth.synthetic_text_ids(tmpl, n, i) for i, n in enumerate([9, 17])]
+        out = _check(bind, m, o, cfg, texts, BASE, 12)
+        m2, o2, cfg2, _ = _pair(bind)
+        try:
+            ref = _check(bind, m2, o2, cfg2, texts, BASE, 12)
+            assert np.array_equal(ref.codes, out.codes)
+        finally:
+            m2.close()
+        short = json.loads(json.dumps(cfg))
+        short["talker_config"]["code_predictor_config"]["sliding_window"] = 4
+        with pytest.raises(QttsError, match="sliding"):
+            Model(short, None, LoaderConfig(dtype="f32"))
     finally:
         m.close()
 
