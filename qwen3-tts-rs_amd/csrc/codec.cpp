@@ -34,15 +34,20 @@ struct CodecState {
     struct Unit {
         Snake a1, a2;
         GemmW c1, c2;
+        DevBuf w1n, w2n;  // narrow blocks: the two convs in the order conv_unit96_kernel reads them
     };
     struct Block {
         Snake s0;
         GemmW ct;
         Unit u[3];
+        // narrow: the block's streams keep their real 96 channels per row instead of the 128 the padded layout gives them (bf16 runs,
+        // last block only: nothing downstream but the output conv reads its rows)
+        bool narrow = false;
     };
     std::vector<Block> blocks;
     Snake sfinal;
     DevBuf final_w;  // [7][CP] f32
+    DevBuf final_wn; // [7][96] f32: the same weights for a narrow last block
     float final_b = 0.f;
     int final_CP = 0;
     int maxpad = 0;  // leading zero rows of the strips inside the vocoder blocks
@@ -182,6 +187,24 @@ void finalize_codec(Model& m) {
                        ERR_SHAPE, "residual unit has the wrong shape");
             s.maxpad = std::max(s.maxpad, 6 * dils[u]);
         }
+        // QTTS_UNIT96=0: the last block in the padded layout like the others
+        static const bool narrow_off = getenv("QTTS_UNIT96") && atoi(getenv("QTTS_UNIT96")) == 0;
+        const int Creal = (int)m.get(p + "1.conv.weight").shape[1];
+        if (!narrow_off && m.dtype == BF16 && b + 1 == c.upsample_rates.size() && Creal == 96 && CP == 128) {
+            blk.narrow = true;
+            for (int u = 0; u < 3; ++u) {
+                const std::string q = p + std::to_string(u + 2) + ".";
+                const std::vector<float> w1 = host_f32(m, q + "conv1.conv.weight"), w2 = host_f32(m, q + "conv2.conv.weight");
+                QTTS_CHECK(w1.size() == (size_t)96 * 96 * 7 && w2.size() == (size_t)96 * 96, ERR_SHAPE, "residual unit has the wrong shape");
+                std::vector<uint16_t> p1((size_t)6 * 21 * 64 * 8), p2((size_t)6 * 3 * 64 * 8);
+                conv_unit96_pack(w1.data(), 7, p1.data(), [](float v) { return f32_to_bf16(v); });
+                conv_unit96_pack(w2.data(), 1, p2.data(), [](float v) { return f32_to_bf16(v); });
+                blk.u[u].w1n.alloc(p1.size() * 2);
+                blk.u[u].w2n.alloc(p2.size() * 2);
+                QTTS_HIP(hipMemcpy(blk.u[u].w1n.p, p1.data(), p1.size() * 2, hipMemcpyHostToDevice));
+                QTTS_HIP(hipMemcpy(blk.u[u].w2n.p, p2.data(), p2.size() * 2, hipMemcpyHostToDevice));
+            }
+        }
     }
     const int nb = (int)c.upsample_rates.size();
     load_snake(m, "decoder.decoder." + std::to_string(nb + 1) + ".", CP, s.sfinal);
@@ -196,6 +219,12 @@ void finalize_codec(Model& m) {
         for (int ci = 0; ci < C; ++ci)
             for (int k = 0; k < 7; ++k) out[(size_t)k * CP + ci] = w[(size_t)ci * 7 + k];
         upload(s.final_w, out, F32);
+        if (!s.blocks.empty() && s.blocks.back().narrow) {
+            std::vector<float> outn((size_t)7 * 96, 0.f);
+            for (int ci = 0; ci < C; ++ci)
+                for (int k = 0; k < 7; ++k) outn[(size_t)k * 96 + ci] = w[(size_t)ci * 7 + k];
+            upload(s.final_wn, outn, F32);
+        }
         s.final_b = host_f32(m, key + "bias")[0];
         s.final_CP = CP;
     }
@@ -576,6 +605,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
     // zero rows per strip.  `xin` is the activated input of the block's transposed conv: Bf for the first block,
     // afterwards the previous block's A viewed from its first valid row.
     const char* xin = (const char*)w.Bf.p;
+    bool last_narrow = false;
     for (int b = 0; b < nb; ++b) {
         const CodecState::Block& blk = s.blocks[(size_t)b];
         const int si = nup + b, so = si + 1;
@@ -586,11 +616,16 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         // the block's units read the f32 stream where the fused kernel covers the block's width
         bool f32in = g.f32_units;
         for (int u = 0; u < 3; ++u) f32in = f32in && conv_unit_supported(dt, CPo, blk.u[u].c1.taps, blk.u[u].c1.dil);
-        zero_pad_rows(w.A.p, S[(size_t)so], Pn, CPo);
+        // a narrow block keeps 96 channels per row in its streams: the transposed conv computes its padded columns and stores the real ones
+        const bool nar = blk.narrow && f32in && b + 1 == nb;
+        const int CW = nar ? 96 : CPo;
+        last_narrow = nar;
+        zero_pad_rows(w.A.p, S[(size_t)so], Pn, CW);
         {
             ConvEpi e{};
             e.M = Min; e.N = blk.ct.N; e.r = blk.ct.r; e.Cout = CPo; e.bias = blk.ct.bias.as<float>();
-            e.lens = d_lenm1(si); e.S_in = S[(size_t)si]; e.S_out = S[(size_t)so]; e.P_out = Pn; e.ld_out = CPo;
+            e.lens = d_lenm1(si); e.S_in = S[(size_t)si]; e.S_out = S[(size_t)so]; e.P_out = Pn; e.ld_out = CW;
+            if (nar) e.Cvalid = CW;
             e.out_f32 = w.Rf.as<float>(); e.out2 = w.A.p; e.alpha_exp = blk.u[0].a1.a.as<float>(); e.beta_den = blk.u[0].a1.den.as<float>();
             if (f32in) e.out2 = nullptr;  // the first unit activates its own input from Rf
             epilogue(e);
@@ -600,15 +635,15 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
         // the unit cannot work in place); otherwise conv1 and conv2 are two launches through Bf.
         if (f32in) {
             // leading rows of every strip are the causal padding of the f32 streams the units read (SnakeBeta of 0 is 0)
-            QTTS_HIP(hipMemset2DAsync(w.Rf.p, (size_t)S[(size_t)so] * CPo * 4, 0, (size_t)Pn * CPo * 4, (size_t)U, st));
-            QTTS_HIP(hipMemset2DAsync(w.Rf2.p, (size_t)S[(size_t)so] * CPo * 4, 0, (size_t)Pn * CPo * 4, (size_t)U, st));
+            QTTS_HIP(hipMemset2DAsync(w.Rf.p, (size_t)S[(size_t)so] * CW * 4, 0, (size_t)Pn * CW * 4, (size_t)U, st));
+            QTTS_HIP(hipMemset2DAsync(w.Rf2.p, (size_t)S[(size_t)so] * CW * 4, 0, (size_t)Pn * CW * 4, (size_t)U, st));
             float* rin = w.Rf.as<float>();
             float* rout = w.Rf2.as<float>();
             for (int u = 0; u < 3; ++u) {
                 const CodecState::Unit& un = blk.u[u];
                 ConvEpi e{};
-                e.M = Mout; e.N = CPo; e.r = 1; e.Cout = CPo; e.bias = un.c2.bias.as<float>();
-                e.resid_f32 = rin; e.lens = d_len(so); e.S_in = S[(size_t)so]; e.S_out = S[(size_t)so]; e.P_out = Pn; e.ld_out = CPo;
+                e.M = Mout; e.N = CW; e.r = 1; e.Cout = CW; e.bias = un.c2.bias.as<float>();
+                e.resid_f32 = rin; e.lens = d_len(so); e.S_in = S[(size_t)so]; e.S_out = S[(size_t)so]; e.P_out = Pn; e.ld_out = CW;
                 if (u < 2) {
                     e.out_f32 = rout;  // the next unit reads (and activates) this stream
                 } else {           // after the last unit only the activated copy is read again
@@ -624,9 +659,11 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
                     QTTS_HIP(hipEventCreate(&pr.b));
                     QTTS_HIP(hipEventRecord(pr.a, st));
                 }
-                const bool ok = launch_conv_unit(st, dt, un.c1.wm(), un.c2.wm(), nullptr, CPo, un.c1.taps, un.c1.dil, un.c1.bias.as<float>(),
-                                                 un.a2.a.as<float>(), un.a2.den.as<float>(), e, rin + (size_t)(Pn - 6 * un.c1.dil) * CPo,
-                                                 un.a1.a.as<float>(), un.a1.den.as<float>());
+                const bool ok = nar ? launch_conv_unit96(st, un.w1n.p, un.w2n.p, un.c1.dil, un.c1.bias.as<float>(), un.a2.a.as<float>(), un.a2.den.as<float>(), e,
+                                                         rin + (size_t)(Pn - 6 * un.c1.dil) * CW, un.a1.a.as<float>(), un.a1.den.as<float>())
+                                    : launch_conv_unit(st, dt, un.c1.wm(), un.c2.wm(), nullptr, CPo, un.c1.taps, un.c1.dil, un.c1.bias.as<float>(),
+                                                       un.a2.a.as<float>(), un.a2.den.as<float>(), e, rin + (size_t)(Pn - 6 * un.c1.dil) * CPo,
+                                                       un.a1.a.as<float>(), un.a1.den.as<float>());
                 QTTS_CHECK(ok, ERR_STATE, "codec decode: fused residual unit refused a shape it reported as supported");
                 if (profiling) {
                     QTTS_HIP(hipEventRecord(pr.b, st));
@@ -704,8 +741,8 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
     }
     // ================= final conv (C -> 1, k = 7) + clamp =================
     const int last = nstage - 1;
-    launch_final_conv(st, dt, w.A.p, s.final_w.as<float>(), s.final_b, d_len(last), U, g.Tmax[(size_t)last], S[(size_t)last], P[(size_t)last],
-                      s.final_CP, w.wav.as<float>(), g.wav_max);
+    launch_final_conv(st, dt, w.A.p, last_narrow ? s.final_wn.as<float>() : s.final_w.as<float>(), s.final_b, d_len(last), U, g.Tmax[(size_t)last],
+                      S[(size_t)last], P[(size_t)last], last_narrow ? 96 : s.final_CP, w.wav.as<float>(), g.wav_max);
     QTTS_HIP(hipEventRecord(ev1, st));
     const long up_total = c.total_upsample();
     for (int u = 0; u < U; ++u) {

@@ -147,9 +147,11 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const T* __restrict__ x
     __syncthreads();
     const int sg = threadIdx.x >> 3, slice = threadIdx.x & 7;
     if (4 * sg >= FC_SAMPLES) return;
-    const int cs = C / 8, c0 = slice * cs;
+    // channels of a slice: a contiguous eighth where that is a whole number of 8-channel pieces, else every eighth piece
+    const bool contiguous = C % 64 == 0;
+    const int cs = contiguous ? C / 8 : C, c0 = contiguous ? slice * cs : slice * 8, cstep = contiguous ? 8 : 64;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < cs; c += 8) {
+    for (int c = 0; c0 + c < (contiguous ? c0 + cs : C); c += cstep) {
         float wk[7][8];
 #pragma unroll
         for (int k = 0; k < 7; ++k) load8(wl + k * C + c0 + c, wk[k]);
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const T* __restrict__ x
 
 void launch_final_conv(hipStream_t st, int dtype, const void* x, const float* w, float bias, const int* nvalid, int U, long Tmax, long S,
                        int P, int C, float* wav, long wav_stride) {
-    QTTS_CHECK(P >= 6 && C % 64 == 0 && U >= 1 && Tmax >= 1, ERR_SHAPE, "final_conv: needs six padding rows and a channel count that is a multiple of 64");
+    QTTS_CHECK(P >= 6 && C % 8 == 0 && C >= 8 && U >= 1 && Tmax >= 1, ERR_SHAPE, "final_conv: needs six padding rows and a channel count that is a multiple of 8");
     const size_t es = dtype == BF16 ? 2 : 4;
     const int per_block = dtype == BF16 ? 128 : 64;
     const size_t lds = (size_t)(per_block + 6) * ((size_t)C * es + 16) + (size_t)7 * C * 4;

@@ -1160,4 +1160,275 @@ bool launch_conv_unit(hipStream_t st, int dtype, WMat W1m, WMat W2m, const void*
     return try_unit<float>(st, (const float*)W1, (const float*)W2, wpk, (const float*)X, C, taps, dil, bias1, alpha2, den2, e);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The fused residual unit at 96 channels without the padding to 128 the general layout would give it (the last vocoder block of
+// the 12 Hz decoder: 44 % of a padded unit's MFMAs and a quarter of its bytes are zeros).  Rows of the f32 stream are 96 floats.
+// Weights come in a layout of their own (conv_unit96_pack): for every 16-column tile and every K step of 32 (7 taps x 3 steps for
+// the dilated conv, 3 steps for the 1x1 conv) one KiB holding each lane's 16-byte A operand of the 16x16x32 MFMA.  Four waves as
+// 2 x 2: row halves of the 64-row tile x three column tiles each.  LDS rows are pitched at 13 pieces of 16 bytes (208 B), which
+// spreads the 16 rows of a fragment read over all banks without a swizzle.  Otherwise the persistent scheme of
+// conv_unit_f32_kernel: halo reused inside LDS, own rows read once in the epilogue's thread layout (192 of the 256 threads: 24
+// float4 per row), residual in registers, unrolled K walk with immediate LDS offsets.
+template <int DIL, int PF, int BPC, bool PREFETCH>
+__global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __restrict__ W1, const uint4* __restrict__ W2,
+                                                               const float* __restrict__ bias1, const float* __restrict__ alpha2,
+                                                               const float* __restrict__ den2, int tiles_per_block, ConvEpi e,
+                                                               const float* __restrict__ Xf, const float* __restrict__ alpha1,
+                                                               const float* __restrict__ den1) {
+    using T = bf16_t;
+    extern __shared__ uint4 tile[];
+    constexpr int C = 96, RT = 64, HALO = 6 * DIL, ROWS_T = RT + HALO, PITCH = 13;  // pieces per LDS row
+    constexpr int STEPS = 21, NT = 3, MT = 2, OP = C + 4, IT = 8;
+    constexpr int tile_slots = (ROWS_T * PITCH + 63) / 64 * 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    const long total = (e.M + RT - 1) / RT;
+    const long t0 = (long)blockIdx.x * tiles_per_block, t1 = t0 + tiles_per_block < total ? t0 + tiles_per_block : total;
+    if (t0 >= total) return;
+    uint4* htile = tile + tile_slots;
+    float* otile = reinterpret_cast<float*>(htile);
+    __shared__ int row_ok[2][RT];
+    __shared__ float sn1[2 * C];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float al = alpha1[c], dn = den1[c];
+        snake_prep<T>(al, dn);
+        sn1[c] = al;
+        sn1[C + c] = dn;
+    }
+    const bool rowthr = threadIdx.x < 192;  // the threads that move rows: 24 float4 per row, eight rows per pass
+    const int c4 = rowthr ? (int)threadIdx.x % 24 : 0, r0 = rowthr ? (int)threadIdx.x / 24 : 0;
+    float res[IT][4], resn[PREFETCH ? IT : 1][4];
+    auto rows_load = [&](const float* src, float (&dst)[IT][4]) {
+        if (!rowthr) return;
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const float4 x = *reinterpret_cast<const float4*>(src + (long)(k * 8 + r0) * C + 4 * c4);
+            dst[k][0] = x.x; dst[k][1] = x.y; dst[k][2] = x.z; dst[k][3] = x.w;
+        }
+    };
+    auto snake4_store = [&](uint4* base, int row, int col, const float (&x)[4]) {
+        const float4 al = *reinterpret_cast<const float4*>(sn1 + col), dn = *reinterpret_cast<const float4*>(sn1 + C + col);
+        const float alv[4] = {al.x, al.y, al.z, al.w}, dnv[4] = {dn.x, dn.y, dn.z, dn.w};
+        u16 h[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[q] = f32_to_bf16_bits(snake_apply<T>(x[q], alv[q], dnv[q]));
+        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(base + row * PITCH) + col * 2) =
+            make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    };
+    rows_load(Xf + (t0 * RT + HALO) * C, res);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < HALO * 24; idx += 256) {  // the first tile's halo comes from memory
+        const int row = idx / 24, col = 4 * (idx - row * 24);
+        const float4 x = *reinterpret_cast<const float4*>(Xf + (t0 * RT + row) * C + col);
+        const float xv[4] = {x.x, x.y, x.z, x.w};
+        snake4_store(tile, row, col, xv);
+    }
+    const uint4* lrow = tile + (32 * wr + r) * PITCH + g;   // the lane's piece of its row of every 16-row tile
+    const uint4* hrow = htile + (32 * wr + r) * PITCH + g;
+    for (long t = t0; t < t1; ++t) {
+        const long m0 = t * RT;
+        // parameters and weight addresses re-derived per tile: hoisted out of the loop they would sit in registers across the K walk
+        const uint4 *W1l = W1, *W2l = W2;
+        const float *bias1l = bias1, *alpha2l = alpha2, *den2l = den2, *bias2l = e.bias, *alnl = e.alpha_exp, *dnnl = e.beta_den;
+        asm volatile("" : "+s"(W1l), "+s"(W2l), "+s"(bias1l), "+s"(alpha2l), "+s"(den2l), "+s"(bias2l), "+s"(alnl), "+s"(dnnl));
+        int* ok = row_ok[t & 1];
+        if ((int)threadIdx.x < RT) {
+            const long m = m0 + threadIdx.x;
+            int v = 0;
+            if (m < e.M) {
+                const long u = m / e.S_in;
+                v = (int)(m - u * e.S_in) < e.lens[u];
+            }
+            ok[threadIdx.x] = v;
+        }
+        if constexpr (!PREFETCH) {
+            if (t > t0) rows_load(Xf + (m0 + HALO) * C, res);
+        }
+        const uint4* w1w = W1l + (size_t)(3 * wc) * STEPS * 64 + lane;  // column tile j, step s: + (j * STEPS + s) * 64
+        bf16x8_t a[PF][NT];
+#pragma unroll
+        for (int s = 0; s < PF - 1; ++s)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) a[s][j] = __builtin_bit_cast(bf16x8_t, w1w[(j * STEPS + s) * 64]);
+        if (rowthr) {
+#pragma unroll
+            for (int k = 0; k < IT; ++k) snake4_store(tile, HALO + k * 8 + r0, 4 * c4, res[k]);
+        }
+        if constexpr (PREFETCH) {
+            if (t + 1 < t1) rows_load(Xf + (m0 + RT + HALO) * C, resn);
+        }
+        f32x4_t acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            if (s + PF - 1 < STEPS) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j) a[(s + PF - 1) % PF][j] = __builtin_bit_cast(bf16x8_t, w1w[(j * STEPS + s + PF - 1) * 64]);
+            }
+            const int tap = s / 3, ks = s % 3;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const bf16x8_t b = __builtin_bit_cast(bf16x8_t, lrow[(16 * i + tap * DIL) * PITCH + ks * 4]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s % PF][j], b, acc[i][j], 0, 0, 0);
+            }
+        }
+        // weights of the 1x1 conv: in flight while the tail of the 7-tap conv is computed
+        bf16x8_t a2[3][NT];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) a2[ks][j] = __builtin_bit_cast(bf16x8_t, W2l[((size_t)(3 * wc + j) * 3 + ks) * 64 + lane]);
+        // tail of the 7-tap conv: bias, SnakeBeta of the bf16 value the unfused layer would have stored, into the second tile
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = (3 * wc + j) * 16 + 4 * g;
+            float bs[4], al[4], dn[4];
+            ld4(bias1l + n, bs);
+            ld4(alpha2l + n, al);
+            ld4(den2l + n, dn);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) snake_prep<T>(al[q], dn[q]);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = 32 * wr + 16 * i + r;
+                u16 h[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float x = bf16_bits_to_f32(f32_to_bf16_bits(acc[i][j][q] + bs[q]));
+                    h[q] = f32_to_bf16_bits(snake_apply<T>(x, al[q], dn[q]));
+                }
+                *reinterpret_cast<uint2*>(reinterpret_cast<char*>(htile + row * PITCH) + n * 2) =
+                    make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+                acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        __syncthreads();  // second tile complete; every wave is past its last read of the input tile
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const bf16x8_t b = __builtin_bit_cast(bf16x8_t, hrow[16 * i * PITCH + ks * 4]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[ks][j], b, acc[i][j], 0, 0, 0);
+            }
+        // the next tile's halo: rows [RT, RT + HALO) move to the front
+        if (t + 1 < t1) {
+            for (int sidx = threadIdx.x; sidx < HALO * PITCH; sidx += 256) tile[sidx] = tile[RT * PITCH + sidx];
+        }
+        __syncthreads();  // every wave is past its reads of the second tile: the f32 staging tile takes its place
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                *reinterpret_cast<f32x4_t*>(otile + (32 * wr + 16 * i + r) * OP + (3 * wc + j) * 16 + 4 * g) = acc[i][j];
+        __syncthreads();
+        if (rowthr) {
+            const int col = 4 * c4;
+            float b2[4], al[4] = {0.f, 0.f, 0.f, 0.f}, dn[4] = {0.f, 0.f, 0.f, 0.f};
+            ld4(bias2l + col, b2);
+            if (e.out2) {
+                ld4(alnl + col, al);
+                ld4(dnnl + col, dn);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) snake_prep<T>(al[q], dn[q]);
+            }
+            const long obase = (m0 + r0 + e.P_out) * C + col;
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+                const int row = k * 8 + r0;
+                if (!ok[row]) continue;
+                const float4 a4 = *reinterpret_cast<const float4*>(otile + row * OP + col);
+                const float v[4] = {a4.x + b2[0] + res[k][0], a4.y + b2[1] + res[k][1], a4.z + b2[2] + res[k][2], a4.w + b2[3] + res[k][3]};
+                const long off = obase + (long)k * 8 * C;
+                if (e.out_f32) *reinterpret_cast<float4*>(e.out_f32 + off) = make_float4(v[0], v[1], v[2], v[3]);
+                if (e.out2) {
+                    float y[4];
+                    u16 h[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        y[q] = snake_apply<T>(v[q], al[q], dn[q]);
+                        h[q] = f32_to_bf16_bits(y[q]);
+                    }
+                    T* o = (T*)e.out2 + off;
+                    *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+                    if (e.out2_lo) {
+                        u16 l[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) l[q] = f32_to_bf16_bits(y[q] - bf16_bits_to_f32(h[q]));
+                        *reinterpret_cast<uint2*>(o + e.out2_lo) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+                    }
+                }
+            }
+        }
+        if constexpr (PREFETCH) {
+#pragma unroll
+            for (int k = 0; k < IT; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) res[k][q] = resn[k][q];
+        }
+    }
+}
+
+namespace {
+template <int DIL, int PF, int BPC, bool PREFETCH>
+bool launch_unit96_cfg(hipStream_t st, const void* W1, const void* W2, const float* bias1, const float* alpha2, const float* den2, const ConvEpi& e,
+                       const float* Xf, const float* alpha1, const float* den1) {
+    constexpr int RT = 64, HALO = 6 * DIL, PITCH = 13;
+    constexpr size_t in_b = (size_t)((RT + HALO) * PITCH + 63) / 64 * 64 * 16;
+    constexpr size_t second = (size_t)RT * PITCH * 16, staging = (size_t)RT * (96 + 4) * 4;
+    constexpr size_t lds = in_b + (second > staging ? second : staging);
+    static_assert(lds * BPC <= (size_t)156 * 1024, "unit tiles of the resident workgroups exceed the LDS of a CU");
+    const long total = (e.M + RT - 1) / RT;
+    if ((long)RT + HALO + 8 > CONV_HALO_SLACK || total > 0x7fffffffL) return false;
+    const long blocks = std::min<long>(total, (long)BPC * 256);
+    const int tpb = (int)((total + blocks - 1) / blocks);
+    const unsigned grid = (unsigned)((total + tpb - 1) / tpb);
+    auto* fn = conv_unit96_kernel<DIL, PF, BPC, PREFETCH>;
+    QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_CEILING));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, st, (const uint4*)W1, (const uint4*)W2, bias1, alpha2, den2, tpb, e, Xf, alpha1, den1);
+    return true;
+}
+// Measured (13.7 M rows per launch, ms per unit): two workgroups per CU with prefetch 4.15 / 4.22 / 4.13 for dilations 1 / 3 / 9,
+// three per CU without prefetch 4.12 / 4.29 / 4.04; the padded 128-channel unit takes 5.2 / 5.4 / 5.4 for the same rows.
+template <int DIL>
+bool launch_unit96_dil(hipStream_t st, const void* W1, const void* W2, const float* bias1, const float* alpha2, const float* den2, const ConvEpi& e,
+                       const float* Xf, const float* alpha1, const float* den1) {
+    return launch_unit96_cfg<DIL, 4, 2, true>(st, W1, W2, bias1, alpha2, den2, e, Xf, alpha1, den1);
+}
+}  // namespace
+
+// Weights of a 96-channel unit in the order conv_unit96_kernel reads them.  w: the conv's f32 weight (96, 96, taps) as the
+// checkpoint holds it; out: 6 column tiles x (taps * 3) steps x 64 lanes x 8 bf16 - lane (r, g) of tile j, step (tap, ks) holds
+// W[16 j + r][32 ks + 8 g .. + 7][tap].
+void conv_unit96_pack(const float* w, int taps, uint16_t* out, uint16_t (*to_bf16)(float)) {
+    const int steps = taps * 3;
+    for (int j = 0; j < 6; ++j)
+        for (int tap = 0; tap < taps; ++tap)
+            for (int ks = 0; ks < 3; ++ks)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r = lane & 15, g = lane >> 4, n = 16 * j + r;
+                    uint16_t* dst = out + (((size_t)j * steps + tap * 3 + ks) * 64 + lane) * 8;
+                    for (int el = 0; el < 8; ++el) dst[el] = to_bf16(w[((size_t)n * 96 + 32 * ks + 8 * g + el) * taps + tap]);
+                }
+}
+
+// One residual unit at 96 unpadded channels on the f32 stream (bf16 matrix cores): e.N = e.Cout = e.ld_out = 96, e.resid_f32 = the
+// input stream, Xf = that stream shifted to the tile's first halo row; W1 / W2 from conv_unit96_pack.  False: shape not covered.
+bool launch_conv_unit96(hipStream_t st, const void* W1, const void* W2, int dil, const float* bias1, const float* alpha2, const float* den2,
+                        const ConvEpi& e, const float* Xf, const float* alpha1, const float* den1) {
+    QTTS_CHECK(W1 && W2 && Xf && bias1 && alpha2 && den2 && alpha1 && den1 && e.lens && e.M >= 1 && e.S_in >= 1, ERR_BAD_ARG, "conv_unit96: null argument");
+    if (!unit_f32_epilogue(e, 96) || e.N != 96 || (const void*)e.resid_f32 == (const void*)e.out_f32 || e.Cvalid != 0) return false;
+    if (Xf != e.resid_f32 + ((long)e.P_out - 6L * dil) * 96) return false;
+    if (dil == 1) return launch_unit96_dil<1>(st, W1, W2, bias1, alpha2, den2, e, Xf, alpha1, den1);
+    if (dil == 3) return launch_unit96_dil<3>(st, W1, W2, bias1, alpha2, den2, e, Xf, alpha1, den1);
+    if (dil == 9) return launch_unit96_dil<9>(st, W1, W2, bias1, alpha2, den2, e, Xf, alpha1, den1);
+    return false;
+}
+
 }  // namespace qtts
