@@ -40,6 +40,21 @@ __device__ __forceinline__ float snake_apply<bf16_t>(float x, float al, float dn
     return fmaf(-dn, c, x + dn);
 }
 
+// four consecutive elements of a model-dtype tensor (aligned to four elements) as f32
+template <typename T>
+__device__ __forceinline__ void load4(const T* p, float (&o)[4]);
+template <>
+__device__ __forceinline__ void load4<float>(const float* p, float (&o)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
+}
+template <>
+__device__ __forceinline__ void load4<bf16_t>(const bf16_t* p, float (&o)[4]) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    o[0] = __uint_as_float(t.x << 16); o[1] = __uint_as_float(t.x & 0xffff0000u);
+    o[2] = __uint_as_float(t.y << 16); o[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+
 __device__ __forceinline__ void ld4(const float* p, float (&o)[4]) {
     const float4 t = *reinterpret_cast<const float4*>(p);
     o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
@@ -81,11 +96,12 @@ template <typename T>
 __device__ __forceinline__ void conv_epi_resid(const ConvEpi& e, long o_off, float (&rr)[4]) {
     if (e.resid) {
         const T* rp = (const T*)e.resid + o_off;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rr[q] = to_f32<T>(rp[q]);
+        load4<T>(rp, rr);
         if (e.resid_lo) {
+            float lo[4];
+            load4<T>(rp + e.resid_lo, lo);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) rr[q] += to_f32<T>(rp[e.resid_lo + q]);
+            for (int q = 0; q < 4; ++q) rr[q] += lo[q];
         }
     } else if (e.resid_f32) {
         ld4(e.resid_f32 + o_off, rr);
@@ -126,28 +142,26 @@ __device__ __forceinline__ void conv_epi_finish(const ConvEpi& e, const EpiCols&
         for (int q = 0; q < 4; ++q) v[q] = rr[q] + v[q];
     }
     if (e.Cvalid && c.co >= e.Cvalid) return;  // columns past the layer's real width are padding
-    if (e.out) {
-        T* o = (T*)e.out + o_off;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) store_split<T>(o + q, e.out_lo, v[q]);
-    }
+    if (e.out) store4_split<T>((T*)e.out + o_off, e.out_lo, v);
     if (e.out_f32) *reinterpret_cast<float4*>(e.out_f32 + o_off) = make_float4(v[0], v[1], v[2], v[3]);
     if (e.out2 && e.act2 == 1) {  // ELU of the value the next op would read
-        T* o = (T*)e.out2 + o_off;
+        float y[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float x = (e.out_f32 || e.resid_f32 || e.out_lo || e.out2_lo) ? v[q] : to_f32<T>(from_f32<T>(v[q]));
-            store_split<T>(o + q, e.out2_lo, x > 0.f ? x : expf(x) - 1.0f);
+            y[q] = x > 0.f ? x : expf(x) - 1.0f;
         }
+        store4_split<T>((T*)e.out2 + o_off, e.out2_lo, y);
     } else if (e.out2) {
-        T* o = (T*)e.out2 + o_off;
+        float y[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             // SnakeBeta in f32 on the value the next op would read: the stored (rounded) one unless the stream is kept in f32
             // or with its remainder
             const float x = (e.out_f32 || e.resid_f32 || e.out_lo || e.out2_lo) ? v[q] : to_f32<T>(from_f32<T>(v[q]));
-            store_split<T>(o + q, e.out2_lo, snake_apply<T>(x, c.al[q], c.den[q]));
+            y[q] = snake_apply<T>(x, c.al[q], c.den[q]);
         }
+        store4_split<T>((T*)e.out2 + o_off, e.out2_lo, y);
     }
 }
 

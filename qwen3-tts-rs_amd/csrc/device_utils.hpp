@@ -80,6 +80,26 @@ __device__ __forceinline__ void store_split(T* p, long lo, float v) {
     p[0] = h;
     if (lo) p[lo] = from_f32<T>(v - to_f32<T>(h));
 }
+// four consecutive elements at once (p and p + lo aligned to four elements): one 8- or 16-byte store per plane
+template <typename T>
+__device__ __forceinline__ void store4_split(T* p, long lo, const float (&v)[4]);
+template <>
+__device__ __forceinline__ void store4_split<float>(float* p, long, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+template <>
+__device__ __forceinline__ void store4_split<bf16_t>(bf16_t* p, long lo, const float (&v)[4]) {
+    u16 h[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h[q] = f32_to_bf16_bits(v[q]);
+    *reinterpret_cast<uint2*>(p) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    if (lo) {
+        u16 l[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) l[q] = f32_to_bf16_bits(v[q] - bf16_bits_to_f32(h[q]));
+        *reinterpret_cast<uint2*>(p + lo) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+    }
+}
 template <typename T>
 __device__ __forceinline__ void store8_split(T* p, long lo, const float (&v)[8]);
 template <>

@@ -40,26 +40,6 @@ __device__ __forceinline__ float quad_rows(float v, F op) {
     return fold_rows(v, op);
 }
 
-template <typename T>
-__device__ __forceinline__ void store4_split(T* p, long lo, const float (&v)[4]);
-template <>
-__device__ __forceinline__ void store4_split<float>(float* p, long, const float (&v)[4]) {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-}
-template <>
-__device__ __forceinline__ void store4_split<bf16_t>(bf16_t* p, long lo, const float (&v)[4]) {
-    u16 h[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) h[e] = f32_to_bf16_bits(v[e]);
-    *reinterpret_cast<uint2*>(p) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
-    if (lo) {
-        u16 l[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) l[e] = f32_to_bf16_bits(v[e] - bf16_bits_to_f32(h[e]));
-        *reinterpret_cast<uint2*>(p + lo) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
-    }
-}
-
 template <typename T, int D, int REP>
 __global__ __launch_bounds__(256) void attention_tile_kernel(const float* __restrict__ q, const Tok* __restrict__ toks,
                                                              const AttnTile* __restrict__ tiles, KVView kv, int layer, int nh,

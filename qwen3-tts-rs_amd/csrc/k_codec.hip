@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void conv_epilogue_kernel(ConvEpi e) {
 }
 
 void launch_conv_epilogue(hipStream_t st, int dtype, const ConvEpi& e) {
-    QTTS_CHECK(e.N % 4 == 0 && e.Cout % 4 == 0 && e.N == e.r * e.Cout && e.M >= 1 && e.Cvalid % 4 == 0, ERR_SHAPE, "conv_epilogue: bad shape");
+    QTTS_CHECK(e.N % 4 == 0 && e.Cout % 4 == 0 && e.N == e.r * e.Cout && e.M >= 1 && e.Cvalid % 4 == 0 && conv_epi_vector_ok(e), ERR_SHAPE, "conv_epilogue: bad shape");
     QTTS_CHECK(e.out2 == nullptr || e.act2 == 1 || (e.alpha_exp && e.beta_den), ERR_BAD_ARG, "conv_epilogue: snake output without parameters");
     QTTS_CHECK(e.acc != nullptr, ERR_BAD_ARG, "conv_epilogue: GEMM output missing");
     const long total = e.M * (long)e.N / 4;

@@ -33,6 +33,13 @@ struct CFrag<bf16_t> {
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v[1], b.v[1], c, 0, 0, 0);
         return c;
     }
+    // one 16-byte half of the B fragment at a time (the halves of a chunk in order: the same sums as mma)
+    static constexpr int HALF_MFMAS = 1;
+    static __device__ __forceinline__ f32x4_t mma_half(const CFrag& a, int half, const uint4& h, f32x4_t c) {
+        bf16x8_t b;
+        __builtin_memcpy(&b, &h, 16);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v[half], b, c, 0, 0, 0);
+    }
 };
 template <>
 struct CFrag<float> {
@@ -48,10 +55,41 @@ struct CFrag<float> {
         for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
         return c;
     }
+    static constexpr int HALF_MFMAS = 4;
+    static __device__ __forceinline__ f32x4_t mma_half(const CFrag& a, int half, const uint4& h, f32x4_t c) {
+        float b[4];
+        __builtin_memcpy(b, &h, 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[4 * half + j], b[j], c, 0, 0, 0);
+        return c;
+    }
 };
 
+// LDS image of an activation tile: rows of vpr 16-byte slots (vpr a multiple of 8), read as MFMA B fragments - lane (r, g) of a
+// 16-row fragment takes slots 2g and 2g + 1 of a row's 64-element chunk.  The LDS serves a 16-byte read of a wave in four groups
+// of 16 lanes, {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32: eight rows of one g and eight rows of the next, and
+// the group takes one cycle when its 16 slots cover all 64 banks.  Two measures give that for every tap offset:
+//  * frag_row: the lanes of a fragment take the 16 rows in an order that puts the even rows into one half of each group and the
+//    odd rows into the other (the epilogues use the same order when they put the accumulators back into rows);
+//  * tile_pcol: inside aligned groups of 16 slots (8 where a row is an odd number of 128-byte halves, which then alternate
+//    between the two halves of the banks) a row's slot pairs are rotated by half the row number and the two slots of a pair are
+//    exchanged in odd rows, so the eight rows of a half land on eight different pairs and the two halves on different slots.
+// (With the plain XOR swizzle slot = col ^ (row & 7) every such read took two cycles per group.)
+__device__ __forceinline__ int frag_row(int lane) {
+    const int q = (lane + 4) & 15;
+    return ((q & 7) << 1) | (q >> 3);
+}
+__device__ __forceinline__ int tile_pcol(int row, int col, int vpr) {  // slot of column `col` (in 16-byte units) inside its row
+    const int m = (vpr & 15) ? 7 : 15, k = (vpr & 15) ? row >> 1 : row;
+    return (col & ~m) | ((((col >> 1) + (k >> 1)) & (m >> 1)) << 1) | ((col ^ k) & 1);
+}
+__device__ __forceinline__ int tile_col_at(int row, int pcol, int vpr) {  // the column that slot `pcol` of a row holds
+    const int m = (vpr & 15) ? 7 : 15, k = (vpr & 15) ? row >> 1 : row;
+    return (pcol & ~m) | ((((pcol >> 1) - (k >> 1)) & (m >> 1)) << 1) | ((pcol ^ k) & 1);
+}
+
 // Input tile -> LDS by DMA (no registers, every load of the tile in flight at once).  A wave instruction fills 64
-// consecutive 16-byte slots, so the XOR swizzle is applied on the source side: slot (row, pcol) takes column pcol ^ (row & 7).
+// consecutive 16-byte slots, so the swizzle is applied on the source side: slot (row, pcol) takes column tile_col_at(row, pcol).
 // The last instruction may run up to 63 slots past `total`: the tile allocation is rounded up to 1 KiB and the rows it
 // reads lie inside the slack every caller keeps readable behind the activations.
 template <typename T>
@@ -62,7 +100,7 @@ __device__ __forceinline__ void tile_load_dma(uint4* tile, const T* src, int C, 
     for (int k = wave; k < nblk; k += 4) {
         const int L = k * 64 + lane;
         const int row = L / vpr, pcol = L - row * vpr;
-        const T* p = src + (long)row * C + (pcol ^ (row & 7)) * VPE;
+        const T* p = src + (long)row * C + tile_col_at(row, pcol, vpr) * VPE;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
                                          (__attribute__((address_space(3))) void*)(tile + k * 64), 16, 0, 0);
     }
@@ -82,7 +120,7 @@ __device__ __forceinline__ void tile_load_snake(uint4* tile, const float* src, i
             const int L = L0 + 256 * k;
             const int Lc = L < total ? L : L0;
             const int row = Lc / vpr, pcol = Lc - row * vpr;
-            col[k] = (pcol ^ (row & 7)) * 8;
+            col[k] = tile_col_at(row, pcol, vpr) * 8;
             const float* p = src + (long)row * C + col[k];
             a[k] = *reinterpret_cast<const float4*>(p);
             b[k] = *reinterpret_cast<const float4*>(p + 4);
@@ -219,7 +257,7 @@ __device__ __forceinline__ void tile_load_snake_keep(uint4* tile, const float* s
             u16 h[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) h[q] = f32_to_bf16_bits(snake_apply<bf16_t>(res[p][k][q], alv[q], dnv[q]));
-            char* dst = reinterpret_cast<char*>(tile + row * vpr + ((col / 8) ^ (row & 7))) + (col % 8) * 2;
+            char* dst = reinterpret_cast<char*>(tile + row * vpr + tile_pcol(row, col / 8, vpr)) + (col % 8) * 2;
             *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
         }
     }
@@ -273,7 +311,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
     constexpr int RT = 16 * MT;
     constexpr int VPE = 16 / (int)sizeof(T);  // elements per 16-byte vector
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, g = lane >> 4;
+    const int r = frag_row(lane), g = lane >> 4;  // r: the lane's row of a 16-row fragment
     int colb;
     long rowb;
     if (!conv_block_tile((e.M + RT - 1) / RT * (e.N / (64 * NT)), e.N / (64 * NT), xcd, colb, rowb)) return;
@@ -314,11 +352,11 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
             if (q < nC) {
                 const int tap = q / cpt, c = q - tap * cpt;
                 const int vb = (c * F::CHUNK + g * F::EPL) / VPE;  // first of the two 16-byte vectors of this lane's fragment
+                const int xr = (r + tap * dil) * vpr + tile_pcol(r + tap * dil, vb, vpr);  // (16 rows further: the same slot of the row)
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const int row = 16 * i + r + tap * dil;
-                    const uint4 h0 = tile[row * vpr + (vb ^ (row & 7))];
-                    const uint4 h1 = tile[row * vpr + ((vb + 1) ^ (row & 7))];
+                    const int x0 = 16 * i * vpr + xr;
+                    const uint4 h0 = tile[x0], h1 = tile[x0 ^ 1];
                     F b;
                     __builtin_memcpy(&b, &h0, 16);
                     __builtin_memcpy((char*)&b + 16, &h1, 16);
@@ -375,7 +413,7 @@ __global__ __launch_bounds__(256, (MT * NT <= 32 && sizeof(T) == 2) ? 2 : 1) voi
     constexpr int RT = 16 * MT * WM;
     constexpr int VPE = 16 / (int)sizeof(T);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, g = lane >> 4;
+    const int r = frag_row(lane), g = lane >> 4;  // r: the lane's row of a 16-row fragment
     const int wm = wave / WN, wn = wave - wm * WN;
     int colb;
     long rowb;
@@ -408,36 +446,53 @@ __global__ __launch_bounds__(256, (MT * NT <= 32 && sizeof(T) == 2) ? 2 : 1) voi
 #pragma unroll
         for (int j = 0; j < NT; ++j) a[0][j].load(wrow[j].chunk(o), wrow[j].hs);
     }
-    for (int q0 = 0; q0 < nC; q0 += PF) {
+    // Phases outside, their steps inside: the tile load's loop (a number of loads the compiler cannot count) stays out of the
+    // loop that streams the weights, where the wait before a step's MFMAs then leaves the chunk requested for the next step in
+    // flight (with both in one loop every other step waited for the loads it had just issued).
+    const int nPhT = nC / per_phase;
+    for (int ph = 0; ph < nPhT; ++ph) {
+        // the phase's channels of the input tile (the first chunk of its weights is already on its way)
+        __syncthreads();
+        tile_load_dma<T>(tile, X + (ph >= nPh ? x_lo : 0L) + m0 * C + (size_t)(ph % nPh) * cph, C, vpr, rows_t * vpr);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        __syncthreads();
+        for (int rem0 = 0; rem0 < per_phase; rem0 += PF) {
 #pragma unroll
-        for (int s = 0; s < PF; ++s) {
-            const int q = q0 + s;
-            if (q >= nC) break;
-            const int ph = q / per_phase, rem = q - ph * per_phase;
-            if (rem == 0) {  // new phase: its channels of the input tile
-                __syncthreads();
-                tile_load_dma<T>(tile, X + (ph >= nPh ? x_lo : 0L) + m0 * C + (size_t)(ph % nPh) * cph, C, vpr, rows_t * vpr);
-                __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-                __syncthreads();
+            for (int s = 0; s < PF; ++s) {
+                const int rem = rem0 + s;
+                if (rem >= per_phase) continue;
+                const int q = ph * per_phase + rem;
+                {   // the next step's weights (the last step of all requests the first chunk again: no branch around the loads)
+                    const int o = woff(q + 1 < nC ? q + 1 : 0);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) a[(s + 1) % PF][j].load(wrow[j].chunk(o), wrow[j].hs);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x020, 2 * NT, 0);  // (first in the step: they have the whole step to arrive)
+                const int tap = rem / cpp, c = rem - tap * cpp;
+                const int vb = (c * F::CHUNK + g * F::EPL) / VPE;
+                const int xr = (wm * (16 * MT) + r + tap * dil) * vpr + tile_pcol(r + tap * dil, vb, vpr);  // (16 rows further: the same slot of the row)
+                // The 2 * MT fragment halves of the step are read LDS_AHEAD halves before their MFMAs: one half ahead (what the
+                // compiler schedules by itself) leaves every read's latency to the other wave of the SIMD to cover.
+                constexpr int NH = 2 * MT, LDS_AHEAD = 3;
+                uint4 hq[NH];
+#pragma unroll
+                for (int t = 0; t < LDS_AHEAD; ++t) hq[t] = tile[(16 * (t >> 1) * vpr + xr) ^ (t & 1)];
+                __builtin_amdgcn_sched_group_barrier(0x100, LDS_AHEAD, 0);
+#pragma unroll
+                for (int t = 0; t < NH; ++t) {
+                    if (t + LDS_AHEAD < NH) {
+                        hq[t + LDS_AHEAD] = tile[(16 * ((t + LDS_AHEAD) >> 1) * vpr + xr) ^ ((t + LDS_AHEAD) & 1)];
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[t >> 1][j] = F::mma_half(a[s][j], t & 1, hq[t], acc[t >> 1][j]);
+                    __builtin_amdgcn_sched_group_barrier(0x008, NT * F::HALF_MFMAS, 0);
+                }
             }
-            if (q + 1 < nC) {
-                const int o = woff(q + 1);
+        }
+        if (per_phase % PF) {  // an odd number of steps: the chunk in flight sits in the other half of the ring
 #pragma unroll
-                for (int j = 0; j < NT; ++j) a[(s + 1) % PF][j].load(wrow[j].chunk(o), wrow[j].hs);
-            }
-            const int tap = rem / cpp, c = rem - tap * cpp;
-            const int vb = (c * F::CHUNK + g * F::EPL) / VPE;
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int row = wm * (16 * MT) + 16 * i + r + tap * dil;
-                const uint4 h0 = tile[row * vpr + (vb ^ (row & 7))];
-                const uint4 h1 = tile[row * vpr + ((vb + 1) ^ (row & 7))];
-                F b;
-                __builtin_memcpy(&b, &h0, 16);
-                __builtin_memcpy((char*)&b + 16, &h1, 16);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[s][j], b, acc[i][j]);
-            }
+            for (int j = 0; j < NT; ++j) a[0][j] = a[1][j];
         }
     }
     // epilogue through LDS, PT column tiles of every wave per pass (see conv_halo_kernel)
@@ -539,7 +594,7 @@ __global__ __launch_bounds__(256, (NT == 3 && sizeof(T) == 2) ? 2 : 1) void conv
     constexpr int vpr = C / VPE;
     constexpr int cpt = C / F::CHUNK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, g = lane >> 4;
+    const int r = frag_row(lane), g = lane >> 4;  // r: the lane's row of a 16-row fragment
     int colb;
     long rowb;
     if (!conv_block_tile((e.M + RT - 1) / RT, 1, xcd, colb, rowb)) return;
@@ -612,11 +667,11 @@ __global__ __launch_bounds__(256, (NT == 3 && sizeof(T) == 2) ? 2 : 1) void conv
             if (q < nC) {
                 const int tap = q / cpt, c = q - tap * cpt;
                 const int vb = (c * F::CHUNK + g * F::EPL) / VPE;
+                const int xr = (r + tap * dil) * vpr + tile_pcol(r + tap * dil, vb, vpr);  // (16 rows further: the same slot of the row)
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
-                    const int row = 16 * i + r + tap * dil;
-                    const uint4 h0 = tile[row * vpr + (vb ^ (row & 7))];
-                    const uint4 h1 = tile[row * vpr + ((vb + 1) ^ (row & 7))];
+                    const int x0 = 16 * i * vpr + xr;
+                    const uint4 h0 = tile[x0], h1 = tile[x0 ^ 1];
                     F b;
                     __builtin_memcpy(&b, &h0, 16);
                     __builtin_memcpy((char*)&b + 16, &h1, 16);
@@ -661,7 +716,7 @@ __global__ __launch_bounds__(256, (NT == 3 && sizeof(T) == 2) ? 2 : 1) void conv
                 const float x = to_f32<T>(from_f32<T>(acc[i][j][q] + bs[q]));
                 y[q] = from_f32<T>(snake_apply<T>(x, al[q], dn[q]));
             }
-            char* dst = reinterpret_cast<char*>(htile + row * vpr + ((n / VPE) ^ (row & 7))) + (n % VPE) * sizeof(T);
+            char* dst = reinterpret_cast<char*>(htile + row * vpr + tile_pcol(row, n / VPE, vpr)) + (n % VPE) * sizeof(T);
             __builtin_memcpy(dst, y, 4 * sizeof(T));
             acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
@@ -670,11 +725,11 @@ __global__ __launch_bounds__(256, (NT == 3 && sizeof(T) == 2) ? 2 : 1) void conv
 #pragma unroll
     for (int c = 0; c < cpt; ++c) {
         const int vb = (c * F::CHUNK + g * F::EPL) / VPE;
+        const int xr = r * vpr + tile_pcol(r, vb, vpr);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-            const int row = 16 * i + r;
-            const uint4 h0 = htile[row * vpr + (vb ^ (row & 7))];
-            const uint4 h1 = htile[row * vpr + ((vb + 1) ^ (row & 7))];
+            const int x0 = 16 * i * vpr + xr;
+            const uint4 h0 = htile[x0], h1 = htile[x0 ^ 1];
             F b;
             __builtin_memcpy(&b, &h0, 16);
             __builtin_memcpy((char*)&b + 16, &h1, 16);
@@ -739,7 +794,7 @@ __device__ __forceinline__ void unit_rows_store(uint4* tile, int C, int vpr, int
             u16 h[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) h[q] = f32_to_bf16_bits(snake_apply<bf16_t>(res[p][k][q], alv[q], dnv[q]));
-            char* dst = reinterpret_cast<char*>(tile + row * vpr + ((col / 8) ^ (row & 7))) + (col % 8) * 2;
+            char* dst = reinterpret_cast<char*>(tile + row * vpr + tile_pcol(row, col / 8, vpr)) + (col % 8) * 2;
             *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
         }
     }
@@ -760,7 +815,7 @@ __global__ __launch_bounds__(256, BPC) void conv_unit_f32_kernel(const bf16_t* _
     static_assert(NT % PT == 0 && HALO < RT, "unit geometry");
     constexpr int tile_slots = (ROWS_T * vpr * 16 + 1023) / 1024 * 64;  // input tile; behind it the second tile / the f32 staging tile
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 15, g = lane >> 4;
+    const int r = frag_row(lane), g = lane >> 4;  // r: the lane's row of a 16-row fragment
     const long total = (e.M + RT - 1) / RT;
     const long t0 = (long)blockIdx.x * tiles_per_block, t1 = t0 + tiles_per_block < total ? t0 + tiles_per_block : total;
     if (t0 >= total) return;
@@ -829,7 +884,7 @@ __global__ __launch_bounds__(256, BPC) void conv_unit_f32_kernel(const bf16_t* _
                 for (int j = 0; j < NT; ++j) a[(q + PF - 1) % PF][j].load(wrow[j].chunk(q + PF - 1), wrow[j].hs);
             }
             const int tap = q / cpt, c = q % cpt;
-            const int x0 = (c * 8 + g * 2) ^ ((r + tap * DIL) & 7);
+            const int x0 = tile_pcol(r + tap * DIL, c * 8 + g * 2, vpr);  // (the same for every 16-row fragment of the tile)
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const uint4* rp = lrow + (16 * i + tap * DIL) * vpr;
@@ -870,7 +925,7 @@ __global__ __launch_bounds__(256, BPC) void conv_unit_f32_kernel(const bf16_t* _
                     const float x = bf16_bits_to_f32(f32_to_bf16_bits(acc[i][j][q] + bs[q]));
                     h[q] = f32_to_bf16_bits(snake_apply<T>(x, al[q], dn[q]));
                 }
-                char* dst = reinterpret_cast<char*>(htile + row * vpr + ((n / 8) ^ (row & 7))) + (n % 8) * 2;
+                char* dst = reinterpret_cast<char*>(htile + row * vpr + tile_pcol(row, n / 8, vpr)) + (n % 8) * 2;
                 *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
                 acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
@@ -878,7 +933,7 @@ __global__ __launch_bounds__(256, BPC) void conv_unit_f32_kernel(const bf16_t* _
         __syncthreads();  // second tile complete; every wave is past its last read of the input tile
 #pragma unroll
         for (int c = 0; c < cpt; ++c) {
-            const int x0 = (c * 8 + g * 2) ^ (r & 7);
+            const int x0 = tile_pcol(r, c * 8 + g * 2, vpr);
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const uint4* rp = hrow + 16 * i * vpr;
@@ -894,7 +949,7 @@ __global__ __launch_bounds__(256, BPC) void conv_unit_f32_kernel(const bf16_t* _
                 for (int j = 0; j < NT; ++j) a2[c % A2][j].load(w2row[j].chunk(c + A2), w2row[j].hs);
             }
         }
-        // the next tile's halo: rows [RT, RT + HALO) move to the front (a shift by a multiple of 8 rows keeps the swizzle)
+        // the next tile's halo: rows [RT, RT + HALO) move to the front (a shift by a multiple of 64 rows keeps the swizzle)
         if (t + 1 < t1) {
             for (int sidx = threadIdx.x; sidx < HALO * vpr; sidx += 256) tile[sidx] = tile[RT * vpr + sidx];
         }
@@ -1110,7 +1165,7 @@ bool try_halo(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, int
 bool launch_conv_halo(hipStream_t st, int dtype, WMat Wm, const void* X, int K, int ldx, int taps, long tap_stride, const ConvEpi& e, long x_lo) {
     const void* W = Wm.p;
     const int wpk = Wm.packed ? 1 : 0;
-    if (taps < 1 || K % taps != 0) return false;
+    if (taps < 1 || K % taps != 0 || !conv_epi_vector_ok(e)) return false;
     const int C = K / taps;
     const int chunk = dtype == BF16 ? 64 : 32;
     if (C != ldx || C % 64 != 0 || C % chunk != 0 || e.N % 64 != 0) return false;
@@ -1153,6 +1208,7 @@ bool launch_conv_unit(hipStream_t st, int dtype, WMat W1m, WMat W2m, const void*
     QTTS_CHECK(W1m.packed == W2m.packed, ERR_BAD_ARG, "conv_unit: the two weight matrices must share a layout");
     const int wpk = W1m.packed ? 1 : 0;
     QTTS_CHECK(W1 && W2 && (X || Xf) && bias1 && alpha2 && den2 && e.lens && e.M >= 1 && e.S_in >= 1, ERR_BAD_ARG, "conv_unit: null argument");
+    if (!conv_epi_vector_ok(e)) return false;
     QTTS_CHECK(!Xf || (dtype == BF16 && alpha1 && den1 && !X), ERR_BAD_ARG, "conv_unit: an f32 input stream needs a bf16 run and the input activation's parameters");
     UnitIn in;
     in.Xf = Xf; in.alpha1 = alpha1; in.den1 = den1;

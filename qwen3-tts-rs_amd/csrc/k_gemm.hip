@@ -480,7 +480,7 @@ void launch_gemm_rows_epi(hipStream_t st, int dtype, WMat Wm, const void* X, int
     const long M = e.M;
     const int N = e.N;
     QTTS_CHECK(M >= 1 && N % 64 == 0 && taps >= 1 && K % taps == 0, ERR_SHAPE, "gemm_rows: N must be a multiple of 64");
-    QTTS_CHECK(e.N % 4 == 0 && e.Cout % 4 == 0 && e.N == e.r * e.Cout && e.Cvalid % 4 == 0 && e.lens && e.S_in >= 1, ERR_SHAPE,
+    QTTS_CHECK(e.N % 4 == 0 && e.Cout % 4 == 0 && e.N == e.r * e.Cout && e.Cvalid % 4 == 0 && e.lens && e.S_in >= 1 && conv_epi_vector_ok(e), ERR_SHAPE,
                "gemm_rows: bad epilogue shape");
     QTTS_CHECK(e.out2 == nullptr || e.act2 == 1 || (e.alpha_exp && e.beta_den), ERR_BAD_ARG, "gemm_rows: snake output without parameters");
     const int chunk = dtype == BF16 ? 64 : 32;

@@ -274,6 +274,12 @@ struct ConvEpi {
     // bf16 runs: element offsets of the remainder planes of resid / out / out2 (see launch_gemm), 0 = single plane
     long resid_lo, out_lo, out2_lo;
 };
+// The element-wise tail moves four consecutive channels per access: channel strides and plane offsets are multiples of four
+// elements (the launchers check it; the buffers themselves come from 256-byte aligned allocations).
+inline bool conv_epi_vector_ok(const ConvEpi& e) {
+    return e.ld_out % 4 == 0 && e.out_lo % 4 == 0 && e.out2_lo % 4 == 0 && e.resid_lo % 4 == 0;
+}
+
 void launch_conv_epilogue(hipStream_t st, int dtype, const ConvEpi& e);
 // GEMM + epilogue in one launch (k_gemm.hip): rows e.M, columns e.N; e.acc is not used
 // x_lo != 0: X carries a remainder plane (tap-addressed kernel only)
