@@ -209,6 +209,75 @@ __device__ __forceinline__ void epi_pass(const ConvEpi& e, const float* otile, c
     }
 }
 
+// The vocoder's usual tail as a pass of its own - bias, optional f32 residual, f32 stream out and / or the SnakeBeta copy in the
+// model dtype (conv_epi_stream_ok): the uniform choices are made once per pass instead of once per four values, a row's output
+// offset comes ready from LDS (row_off: element offset of the row's first output row, < 0 = no output), and the instruction
+// stream is a fraction of the general tail's (whose eight unrolled copies with every activation inlined do not fit the
+// instruction cache).  Values and stores are the general tail's.
+template <typename T, int RT, int GPR, int OP>
+__device__ __forceinline__ void epi_pass_stream(const ConvEpi& e, const float* otile, const long* row_off, int n0) {
+    static_assert(256 % GPR == 0 && RT % (256 / GPR) == 0, "epilogue pass geometry");
+    constexpr int RPI = 256 / GPR, IT = RT / RPI;
+    constexpr int U = sizeof(T) == 4 ? 1 : (IT >= 8 ? 8 : IT);
+    static_assert(IT % U == 0, "epilogue pass geometry");
+    const int c4 = threadIdx.x % GPR, r0 = threadIdx.x / GPR;
+    EpiCols pc;
+    conv_epi_cols<T>(e, n0 + 4 * c4, pc);
+    if (e.Cvalid && pc.co >= e.Cvalid) return;  // columns past the layer's real width are padding
+    const long coff = (long)pc.j * e.ld_out + pc.co;
+    const float* rs = e.resid_f32 ? e.resid_f32 + coff : nullptr;
+    float* of = e.out_f32 ? e.out_f32 + coff : nullptr;
+    T* o2 = e.out2 ? (T*)e.out2 + coff : nullptr;
+    const long lo2 = e.out2_lo;
+    const bool exact = e.out_f32 || e.resid_f32 || e.out_lo || lo2;  // SnakeBeta of the f32 value (else of the value rounded to the model dtype)
+    for (int it0 = 0; it0 < IT; it0 += U) {
+        float rr[U][4];
+        long off[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            off[k] = row_off[(it0 + k) * RPI + r0];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rr[k][q] = 0.f;
+            if (rs && off[k] >= 0) ld4(rs + off[k], rr[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            if (off[k] < 0) continue;
+            const float4 a4 = *reinterpret_cast<const float4*>(otile + ((it0 + k) * RPI + r0) * OP + 4 * c4);
+            float v[4] = {a4.x + pc.bias[0], a4.y + pc.bias[1], a4.z + pc.bias[2], a4.w + pc.bias[3]};
+            if (rs) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = rr[k][q] + v[q];
+            }
+            if (of) *reinterpret_cast<float4*>(of + off[k]) = make_float4(v[0], v[1], v[2], v[3]);
+            if (o2) {
+                float y[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) y[q] = snake_apply<T>(exact ? v[q] : to_f32<T>(from_f32<T>(v[q])), pc.al[q], pc.den[q]);
+                store4_split<T>(o2 + off[k], lo2, y);
+            }
+        }
+    }
+}
+static bool conv_epi_stream_ok(const ConvEpi& e) {  // QTTS_EPI_STREAM=0: every conv through the general tail
+    static const bool off = getenv("QTTS_EPI_STREAM") && atoi(getenv("QTTS_EPI_STREAM")) == 0;
+    return !off && e.bias && !e.bias_u && !e.scale && e.act == 0 && !e.resid && !e.out && (e.out_f32 || e.out2) && (!e.out2 || e.act2 == 0);
+}
+// element offset of the first output row of every tile row (the general tail's conv_epi_offset without its column part)
+template <int RT>
+__device__ __forceinline__ void epi_row_offsets(const ConvEpi& e, long m0, long* row_off) {
+    for (int t = threadIdx.x; t < RT; t += 256) {
+        const long m = m0 + t;
+        long o = -1;
+        if (m < e.M) {
+            const long u = m / e.S_in;
+            const int tp = (int)(m - u * e.S_in);
+            if (tp < e.lens[u]) o = (u * e.S_out + e.P_out + (long)tp * e.r) * e.ld_out;
+        }
+        row_off[t] = o;
+    }
+}
+
 // The same pass with the residual rows already in registers (res[k] = the four values of row k * RPI + r0 the thread read when
 // it built the input tile): nothing is loaded from the residual stream.
 template <typename T, int RT, int GPR, int OP>
@@ -303,7 +372,7 @@ __device__ __forceinline__ void epi_rows_finish(const ConvEpi& e, const EpiCols&
     }
 }
 
-template <typename T, int MT, int NT>
+template <typename T, int MT, int NT, bool STREAM = false>
 __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W, int wpk, const T* __restrict__ X, int K, int C, int taps, int dil,
                                                         int xcd, ConvEpi e) {
     using F = CFrag<T>;
@@ -373,8 +442,12 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
     constexpr int CP = 64 * PT, OP = CP + 4;  // columns per pass, padded f32 row pitch
     static_assert(NT % PT == 0, "column tiles per wave must be a multiple of the tiles per epilogue pass");
     float* otile = reinterpret_cast<float*>(tile);
-    __shared__ int row_u[RT], row_tp[RT];  // strip and step of every tile row (tp < 0: row holds no output)
-    if ((int)threadIdx.x < RT) {
+    __shared__ long row_mem[RT];  // per tile row: strip and step (step < 0: the row holds no output), or its output offset
+    int* row_u = reinterpret_cast<int*>(row_mem);
+    int* row_tp = row_u + RT;
+    if constexpr (STREAM) {
+        epi_row_offsets<RT>(e, m0, row_mem);
+    } else if ((int)threadIdx.x < RT) {
         const long m = m0 + threadIdx.x;
         int uu = 0, tt = -1;
         if (m < e.M) {
@@ -395,7 +468,8 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
             for (int jj = 0; jj < PT; ++jj)
                 *reinterpret_cast<f32x4_t*>(otile + (16 * i + r) * OP + (4 * jj + wave) * 16 + 4 * g) = acc[i][p * PT + jj];
         __syncthreads();
-        epi_pass<T, RT, CP / 4, OP>(e, otile, row_u, row_tp, nb + p * CP);
+        if constexpr (STREAM) epi_pass_stream<T, RT, CP / 4, OP>(e, otile, row_mem, nb + p * CP);
+        else epi_pass<T, RT, CP / 4, OP>(e, otile, row_u, row_tp, nb + p * CP);
     }
 }
 
@@ -404,7 +478,7 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
 // weight loads per MFMA half of those of the kernel above (where all four waves read the same input fragments), which is
 // what bounds it.  The input channels are walked in phases of `cph` channels so that the tile of 256 rows + halo stays in LDS
 // whatever the layer's width; the weight stream is prefetched across phase boundaries.
-template <typename T, int MT, int NT, int WN>
+template <typename T, int MT, int NT, int WN, bool STREAM = false>
 __global__ __launch_bounds__(256, (MT * NT <= 32 && sizeof(T) == 2) ? 2 : 1) void conv_tile_kernel(const T* __restrict__ W, int wpk, const T* __restrict__ X, int K, int C, int taps, int dil,
                                                         int cph, long x_lo, int xcd, ConvEpi e) {
     using F = CFrag<T>;
@@ -450,12 +524,15 @@ __global__ __launch_bounds__(256, (MT * NT <= 32 && sizeof(T) == 2) ? 2 : 1) voi
     // loop that streams the weights, where the wait before a step's MFMAs then leaves the chunk requested for the next step in
     // flight (with both in one loop every other step waited for the loads it had just issued).
     const int nPhT = nC / per_phase;
+    QTTS_TS(0);
     for (int ph = 0; ph < nPhT; ++ph) {
         // the phase's channels of the input tile (the first chunk of its weights is already on its way)
         __syncthreads();
         tile_load_dma<T>(tile, X + (ph >= nPh ? x_lo : 0L) + m0 * C + (size_t)(ph % nPh) * cph, C, vpr, rows_t * vpr);
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
         __syncthreads();
+        if (ph == 0) QTTS_TS(1);
+        if (ph == 1) QTTS_TS(2);
         for (int rem0 = 0; rem0 < per_phase; rem0 += PF) {
 #pragma unroll
             for (int s = 0; s < PF; ++s) {
@@ -496,21 +573,28 @@ __global__ __launch_bounds__(256, (MT * NT <= 32 && sizeof(T) == 2) ? 2 : 1) voi
         }
     }
     // epilogue through LDS, PT column tiles of every wave per pass (see conv_halo_kernel)
+    QTTS_TS(3);
     constexpr int PT = NT % 2 == 0 ? 2 : 1;
     constexpr int CP = 16 * WN * PT, OP = CP + 4;
     float* otile = reinterpret_cast<float*>(tile);
-    __shared__ int row_u[RT], row_tp[RT];
-    for (int t = threadIdx.x; t < RT; t += 256) {
-        const long m = m0 + t;
-        int uu = 0, tt = -1;
-        if (m < e.M) {
-            const long u = m / e.S_in;
-            const int tp = (int)(m - u * e.S_in);
-            uu = (int)u;
-            tt = tp < e.lens[u] ? tp : -1;
+    __shared__ long row_mem[RT];  // per tile row: strip and step, or (STREAM) its output offset
+    int* row_u = reinterpret_cast<int*>(row_mem);
+    int* row_tp = row_u + RT;
+    if constexpr (STREAM) {
+        epi_row_offsets<RT>(e, m0, row_mem);
+    } else {
+        for (int t = threadIdx.x; t < RT; t += 256) {
+            const long m = m0 + t;
+            int uu = 0, tt = -1;
+            if (m < e.M) {
+                const long u = m / e.S_in;
+                const int tp = (int)(m - u * e.S_in);
+                uu = (int)u;
+                tt = tp < e.lens[u] ? tp : -1;
+            }
+            row_u[t] = uu;
+            row_tp[t] = tt;
         }
-        row_u[t] = uu;
-        row_tp[t] = tt;
     }
 #pragma unroll
     for (int p = 0; p < NT / PT; ++p) {
@@ -521,8 +605,11 @@ __global__ __launch_bounds__(256, (MT * NT <= 32 && sizeof(T) == 2) ? 2 : 1) voi
             for (int jj = 0; jj < PT; ++jj)
                 *reinterpret_cast<f32x4_t*>(otile + (wm * (16 * MT) + 16 * i + r) * OP + (jj * WN + wn) * 16 + 4 * g) = acc[i][p * PT + jj];
         __syncthreads();
-        epi_pass<T, RT, CP / 4, OP>(e, otile, row_u, row_tp, nb + p * CP);
+        if constexpr (STREAM) epi_pass_stream<T, RT, CP / 4, OP>(e, otile, row_mem, nb + p * CP);
+        else epi_pass<T, RT, CP / 4, OP>(e, otile, row_u, row_tp, nb + p * CP);
+        if (p == 0) QTTS_TS(4);
     }
+    QTTS_TS(5);
 }
 
 template <typename T, int MT, int NT, int WN>
@@ -534,7 +621,7 @@ void launch_tile(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, 
     const int xcd = conv_xcd_order();
     unsigned grid = 0;
     QTTS_CHECK(conv_grid(gy * (e.N / (16 * NT * WN)), xcd, grid), ERR_SHAPE, "conv: too many tiles for one launch");
-    auto* fn = conv_tile_kernel<T, MT, NT, WN>;
+    auto* fn = conv_epi_stream_ok(e) ? conv_tile_kernel<T, MT, NT, WN, true> : conv_tile_kernel<T, MT, NT, WN, false>;
     // the same ceiling from every caller: streams of several host threads launch this kernel with different tile sizes
     QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_CEILING));
     hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, st, W, wpk, X, K, C, taps, dil, cph, x_lo, xcd, e);
@@ -1124,7 +1211,8 @@ void launch_halo(hipStream_t st, const T* W, int wpk, const T* X, int K, int C, 
     const int xcd = conv_xcd_order();
     unsigned grid = 0;
     QTTS_CHECK(conv_grid(gy * (e.N / (64 * NT)), xcd, grid), ERR_SHAPE, "conv: too many tiles for one launch");
-    hipLaunchKernelGGL((conv_halo_kernel<T, MT, NT>), dim3(grid), dim3(256), lds, st, W, wpk, X, K, C, taps, dil, xcd, e);
+    auto* fn = conv_epi_stream_ok(e) ? conv_halo_kernel<T, MT, NT, true> : conv_halo_kernel<T, MT, NT, false>;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, st, W, wpk, X, K, C, taps, dil, xcd, e);
 }
 
 template <typename T>
