@@ -930,9 +930,13 @@ __global__ __launch_bounds__(256, BPC) void conv_unit_f32_kernel(const bf16_t* _
         // registers across the K walk and push the kernel into scratch.  Passing the pointers through an empty asm statement
         // makes them opaque per iteration: every tile re-derives its addresses (a handful of scalar instructions) and re-reads
         // the parameters from cache where it needs them.
-        const bf16_t *W1l = W1, *W2l = W2;
-        const float *bias1l = bias1, *alpha2l = alpha2, *den2l = den2, *bias2l = e.bias, *alnl = e.alpha_exp, *dnnl = e.beta_den;
-        asm volatile("" : "+s"(W1l), "+s"(W2l), "+s"(bias1l), "+s"(alpha2l), "+s"(den2l), "+s"(bias2l), "+s"(alnl), "+s"(dnnl));
+        // (an opaque zero offset rather than opaque pointers: a pointer that went through the asm statement is no longer known
+        // to point to global memory, and its loads become flat loads, which count on both the vector-memory and the LDS counter
+        // and force every wait around them to drain both)
+        long z = 0;
+        asm volatile("" : "+s"(z));
+        const bf16_t *W1l = W1 + z, *W2l = W2 + z;
+        const float *bias1l = bias1 + z, *alpha2l = alpha2 + z, *den2l = den2 + z, *bias2l = e.bias + z, *alnl = e.alpha_exp + z, *dnnl = e.beta_den + z;
         WFragPtr<T> wrow[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) wrow[j] = WFragPtr<T>(W1l, (4 * j + wave_s) * 16, K, lane, wpk);
@@ -1309,8 +1313,9 @@ bool launch_conv_unit(hipStream_t st, int dtype, WMat W1m, WMat W2m, const void*
 // the 12 Hz decoder: 44 % of a padded unit's MFMAs and a quarter of its bytes are zeros).  Rows of the f32 stream are 96 floats.
 // Weights come in a layout of their own (conv_unit96_pack): for every 16-column tile and every K step of 32 (7 taps x 3 steps for
 // the dilated conv, 3 steps for the 1x1 conv) one KiB holding each lane's 16-byte A operand of the 16x16x32 MFMA.  Four waves as
-// 2 x 2: row halves of the 64-row tile x three column tiles each.  LDS rows are pitched at 13 pieces of 16 bytes (208 B), which
-// spreads the 16 rows of a fragment read over all banks without a swizzle.  Otherwise the persistent scheme of
+// 2 x 2: row halves of the 64-row tile x three column tiles each.  LDS rows are pitched at 14 pieces of 16 bytes (224 B): a
+// 16-lane group of a fragment read (eight rows of one piece, eight of the next, see tile_pcol) then covers all 64 banks without
+// a swizzle, whatever the tap offset (at 13 pieces a third of the groups took two cycles).  Otherwise the persistent scheme of
 // conv_unit_f32_kernel: halo reused inside LDS, own rows read once in the epilogue's thread layout (192 of the 256 threads: 24
 // float4 per row), residual in registers, unrolled K walk with immediate LDS offsets.
 template <int DIL, int PF, int BPC, bool PREFETCH>
@@ -1321,7 +1326,7 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
                                                                const float* __restrict__ den1) {
     using T = bf16_t;
     extern __shared__ uint4 tile[];
-    constexpr int C = 96, RT = 64, HALO = 6 * DIL, ROWS_T = RT + HALO, PITCH = 13;  // pieces per LDS row
+    constexpr int C = 96, RT = 64, HALO = 6 * DIL, ROWS_T = RT + HALO, PITCH = 14;  // pieces per LDS row
     constexpr int STEPS = 21, NT = 3, MT = 2, OP = C + 4, IT = 8;
     constexpr int tile_slots = (ROWS_T * PITCH + 63) / 64 * 64;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1343,8 +1348,9 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
     const bool rowthr = threadIdx.x < 192;  // the threads that move rows: 24 float4 per row, eight rows per pass
     const int c4 = rowthr ? (int)threadIdx.x % 24 : 0, r0 = rowthr ? (int)threadIdx.x / 24 : 0;
     float res[IT][4], resn[PREFETCH ? IT : 1][4];
+    // (threads 192 .. 255 read the first float4 of rows 0, 8, ... again instead of branching around the loads: with a branch in
+    // between the compiler cannot count the loads in flight and every later wait becomes a wait for all of them)
     auto rows_load = [&](const float* src, float (&dst)[IT][4]) {
-        if (!rowthr) return;
 #pragma unroll
         for (int k = 0; k < IT; ++k) {
             const float4 x = *reinterpret_cast<const float4*>(src + (long)(k * 8 + r0) * C + 4 * c4);
@@ -1373,9 +1379,10 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
     for (long t = t0; t < t1; ++t) {
         const long m0 = t * RT;
         // parameters and weight addresses re-derived per tile: hoisted out of the loop they would sit in registers across the K walk
-        const uint4 *W1l = W1, *W2l = W2;
-        const float *bias1l = bias1, *alpha2l = alpha2, *den2l = den2, *bias2l = e.bias, *alnl = e.alpha_exp, *dnnl = e.beta_den;
-        asm volatile("" : "+s"(W1l), "+s"(W2l), "+s"(bias1l), "+s"(alpha2l), "+s"(den2l), "+s"(bias2l), "+s"(alnl), "+s"(dnnl));
+        long z = 0;  // (an opaque zero offset, not opaque pointers: see conv_unit_f32_kernel)
+        asm volatile("" : "+s"(z));
+        const uint4 *W1l = W1 + z, *W2l = W2 + z;
+        const float *bias1l = bias1 + z, *alpha2l = alpha2 + z, *den2l = den2 + z, *bias2l = e.bias + z, *alnl = e.alpha_exp + z, *dnnl = e.beta_den + z;
         int* ok = row_ok[t & 1];
         if ((int)threadIdx.x < RT) {
             const long m = m0 + threadIdx.x;
@@ -1399,27 +1406,40 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
 #pragma unroll
             for (int k = 0; k < IT; ++k) snake4_store(tile, HALO + k * 8 + r0, 4 * c4, res[k]);
         }
-        if constexpr (PREFETCH) {
-            if (t + 1 < t1) rows_load(Xf + (m0 + RT + HALO) * C, resn);
-        }
+        if constexpr (PREFETCH) rows_load(Xf + ((t + 1 < t1 ? m0 + RT : m0) + HALO) * C, resn);  // (the last tile reads its own rows again)
         f32x4_t acc[MT][NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         __syncthreads();
+        // The K walk step by step, every step a scheduling region of its own: its weight loads for PF - 1 steps ahead, its LDS
+        // reads for two steps ahead, then its MFMAs.  Without the region boundaries the scheduler sinks loads and reads next to
+        // their uses, and every MFMA group then starts with a full LDS round trip.
+        {
+            constexpr int NPC = STEPS * MT, LDS_AHEAD = 2 * MT;
+            bf16x8_t bq[NPC + LDS_AHEAD];
+            auto frag = [&](int t) {
+                const int s = t / MT, i = t % MT, tap = s / 3, ks = s % 3;
+                return __builtin_bit_cast(bf16x8_t, lrow[(16 * i + tap * DIL) * PITCH + ks * 4]);
+            };
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) {
-            if (s + PF - 1 < STEPS) {
+            for (int t = 0; t < LDS_AHEAD; ++t) bq[t] = frag(t);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) a[(s + PF - 1) % PF][j] = __builtin_bit_cast(bf16x8_t, w1w[(j * STEPS + s + PF - 1) * 64]);
-            }
-            const int tap = s / 3, ks = s % 3;
+            for (int s = 0; s < STEPS; ++s) {
+                if (s + PF - 1 < STEPS) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const bf16x8_t b = __builtin_bit_cast(bf16x8_t, lrow[(16 * i + tap * DIL) * PITCH + ks * 4]);
+                    for (int j = 0; j < NT; ++j) a[(s + PF - 1) % PF][j] = __builtin_bit_cast(bf16x8_t, w1w[(j * STEPS + s + PF - 1) * 64]);
+                }
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s % PF][j], b, acc[i][j], 0, 0, 0);
+                for (int i = 0; i < MT; ++i)
+                    if (s * MT + i + LDS_AHEAD < NPC) bq[s * MT + i + LDS_AHEAD] = frag(s * MT + i + LDS_AHEAD);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s % PF][j], bq[s * MT + i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // weights of the 1x1 conv: in flight while the tail of the 7-tap conv is computed
@@ -1472,23 +1492,42 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
             for (int j = 0; j < NT; ++j)
                 *reinterpret_cast<f32x4_t*>(otile + (32 * wr + 16 * i + r) * OP + (3 * wc + j) * 16 + 4 * g) = acc[i][j];
         __syncthreads();
-        if (rowthr) {
+        // The residual rows (and the next tile's) have been in flight since before the K walk.  One wait here, and the values
+        // are passed through an empty asm statement: behind the conditional stores below the compiler can no longer count, and
+        // would wait for everything in flight - the previous row's stores included - before every row.
+        {
             const int col = 4 * c4;
             float b2[4], al[4] = {0.f, 0.f, 0.f, 0.f}, dn[4] = {0.f, 0.f, 0.f, 0.f};
             ld4(bias2l + col, b2);
             if (e.out2) {
                 ld4(alnl + col, al);
                 ld4(dnnl + col, dn);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(b2[q]), "+v"(al[q]), "+v"(dn[q]));
+#pragma unroll
+            for (int k = 0; k < IT; ++k)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    asm volatile("" : "+v"(res[k][q]));
+                    if constexpr (PREFETCH) asm volatile("" : "+v"(resn[k][q]));
+                }
+            if (e.out2) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) snake_prep<T>(al[q], dn[q]);
             }
+          if (rowthr) {
             const long obase = (m0 + r0 + e.P_out) * C + col;
 #pragma unroll
             for (int k = 0; k < IT; ++k) {
                 const int row = k * 8 + r0;
                 if (!ok[row]) continue;
                 const float4 a4 = *reinterpret_cast<const float4*>(otile + row * OP + col);
-                const float v[4] = {a4.x + b2[0] + res[k][0], a4.y + b2[1] + res[k][1], a4.z + b2[2] + res[k][2], a4.w + b2[3] + res[k][3]};
+                // (the sum replaces the residual in its registers: every row's store then reads registers of its own, and the
+                // next row's LDS read need not wait until this row's store has fetched its data)
+                float (&v)[4] = res[k];
+                v[0] = a4.x + b2[0] + v[0]; v[1] = a4.y + b2[1] + v[1]; v[2] = a4.z + b2[2] + v[2]; v[3] = a4.w + b2[3] + v[3];
                 const long off = obase + (long)k * 8 * C;
                 if (e.out_f32) *reinterpret_cast<float4*>(e.out_f32 + off) = make_float4(v[0], v[1], v[2], v[3]);
                 if (e.out2) {
@@ -1509,6 +1548,7 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
                     }
                 }
             }
+          }
         }
         if constexpr (PREFETCH) {
 #pragma unroll
@@ -1523,7 +1563,7 @@ namespace {
 template <int DIL, int PF, int BPC, bool PREFETCH>
 bool launch_unit96_cfg(hipStream_t st, const void* W1, const void* W2, const float* bias1, const float* alpha2, const float* den2, const ConvEpi& e,
                        const float* Xf, const float* alpha1, const float* den1) {
-    constexpr int RT = 64, HALO = 6 * DIL, PITCH = 13;
+    constexpr int RT = 64, HALO = 6 * DIL, PITCH = 14;
     constexpr size_t in_b = (size_t)((RT + HALO) * PITCH + 63) / 64 * 64 * 16;
     constexpr size_t second = (size_t)RT * PITCH * 16, staging = (size_t)RT * (96 + 4) * 4;
     constexpr size_t lds = in_b + (second > staging ? second : staging);
