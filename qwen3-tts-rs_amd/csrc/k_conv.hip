@@ -968,23 +968,37 @@ __global__ __launch_bounds__(256, BPC) void conv_unit_f32_kernel(const bf16_t* _
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         __syncthreads();
+        // The walk in pieces of one 16-byte fragment half (NT MFMAs), each a scheduling region of its own: a step's first piece
+        // issues the weight loads for PF - 1 steps ahead, every piece the LDS read of the piece LDS_AHEAD further on, then its
+        // MFMAs.  (In one region the scheduler sinks loads and reads next to their uses, and every MFMA group starts with a full
+        // LDS round trip.)
+        {
+            constexpr int PPS = 2 * MT, NPC = nC * PPS, LDS_AHEAD = 3;  // pieces per step, pieces
+            auto piece = [&](int p) {
+                const int q = p / PPS, i = (p % PPS) >> 1, hh = p & 1;
+                const int tap = q / cpt, c = q % cpt;
+                const int x0 = tile_pcol(r + tap * DIL, c * 8 + g * 2, vpr);  // (the same for every 16-row fragment of the tile)
+                return lrow[(16 * i + tap * DIL) * vpr + (x0 ^ hh)];
+            };
+            static_assert(PPS % 4 == 0 && LDS_AHEAD < 4, "ring of four pieces");
+            uint4 hq[4];  // ring: piece p sits in hq[p % 4]
 #pragma unroll
-        for (int q = 0; q < nC; ++q) {
-            if (q + PF - 1 < nC) {
+            for (int p = 0; p < LDS_AHEAD; ++p) hq[p] = piece(p);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) a[(q + PF - 1) % PF][j].load(wrow[j].chunk(q + PF - 1), wrow[j].hs);
-            }
-            const int tap = q / cpt, c = q % cpt;
-            const int x0 = tile_pcol(r + tap * DIL, c * 8 + g * 2, vpr);  // (the same for every 16-row fragment of the tile)
+            for (int q = 0; q < nC; ++q) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const uint4* rp = lrow + (16 * i + tap * DIL) * vpr;
-                const uint4 h0 = rp[x0], h1 = rp[x0 ^ 1];
-                F b;
-                __builtin_memcpy(&b, &h0, 16);
-                __builtin_memcpy((char*)&b + 16, &h1, 16);
+                for (int pp = 0; pp < PPS; ++pp) {
+                    const int p = q * PPS + pp, i = pp >> 1, hh = pp & 1;
+                    if (pp == 0 && q + PF - 1 < nC) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[q % PF][j], b, acc[i][j]);
+                        for (int j = 0; j < NT; ++j) a[(q + PF - 1) % PF][j].load(wrow[j].chunk(q + PF - 1), wrow[j].hs);
+                    }
+                    if (p + LDS_AHEAD < NPC) hq[(pp + LDS_AHEAD) % 4] = piece(p + LDS_AHEAD);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = F::mma_half(a[q % PF][j], hh, hq[pp % 4], acc[i][j]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         // weights of the 1x1 conv: in flight while the tail of the 7-tap conv is computed
