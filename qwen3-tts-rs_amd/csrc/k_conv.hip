@@ -509,17 +509,9 @@ __global__ __launch_bounds__(256, (MT * NT <= 32 && sizeof(T) == 2) ? 2 : 1) voi
     WFragPtr<T> wrow[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) wrow[j] = WFragPtr<T>(W, nb + (j * WN + wn) * 16, K, lane, wpk);
-    // chunk q of the K walk (phase ph, tap, chunk c inside the phase's channels): its chunk index in a weight row
-    auto woff = [&](int q) {
-        const int ph = q / per_phase, rem = q - ph * per_phase;
-        const int tap = rem / cpp, c = rem - tap * cpp;
-        return (tap * C + (ph % nPh) * cph) / F::CHUNK + c;
-    };
-    {
-        const int o = woff(0);
+    // the chunk of step (phase ph, tap, chunk c inside the phase's channels) in a weight row: (tap * C + (ph % nPh) * cph) / CHUNK + c
 #pragma unroll
-        for (int j = 0; j < NT; ++j) a[0][j].load(wrow[j].chunk(o), wrow[j].hs);
-    }
+    for (int j = 0; j < NT; ++j) a[0][j].load(wrow[j].chunk(0), wrow[j].hs);
     // Phases outside, their steps inside: the tile load's loop (a number of loads the compiler cannot count) stays out of the
     // loop that streams the weights, where the wait before a step's MFMAs then leaves the chunk requested for the next step in
     // flight (with both in one loop every other step waited for the loads it had just issued).
@@ -533,19 +525,23 @@ __global__ __launch_bounds__(256, (MT * NT <= 32 && sizeof(T) == 2) ? 2 : 1) voi
         __syncthreads();
         if (ph == 0) QTTS_TS(1);
         if (ph == 1) QTTS_TS(2);
+        // (tap, c) of the step and the weight chunk of the next one are counted along: divisions here would be a chain of some
+        // seventy scalar instructions per step in front of the wave's MFMAs
+        const int base = (ph % nPh) * (cph / F::CHUNK), base_next = ((ph + 1 < nPhT ? ph + 1 : 0) % nPh) * (cph / F::CHUNK);
+        int tap = 0, c = 0;
         for (int rem0 = 0; rem0 < per_phase; rem0 += PF) {
 #pragma unroll
             for (int s = 0; s < PF; ++s) {
                 const int rem = rem0 + s;
                 if (rem >= per_phase) continue;
-                const int q = ph * per_phase + rem;
+                int ntap = tap, nc = c + 1;
+                if (nc == cpp) { nc = 0; ++ntap; }
                 {   // the next step's weights (the last step of all requests the first chunk again: no branch around the loads)
-                    const int o = woff(q + 1 < nC ? q + 1 : 0);
+                    const int o = rem + 1 < per_phase ? ntap * (C / F::CHUNK) + base + nc : base_next;
 #pragma unroll
                     for (int j = 0; j < NT; ++j) a[(s + 1) % PF][j].load(wrow[j].chunk(o), wrow[j].hs);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x020, 2 * NT, 0);  // (first in the step: they have the whole step to arrive)
-                const int tap = rem / cpp, c = rem - tap * cpp;
                 const int vb = (c * F::CHUNK + g * F::EPL) / VPE;
                 const int xr = (wm * (16 * MT) + r + tap * dil) * vpr + tile_pcol(r + tap * dil, vb, vpr);  // (16 rows further: the same slot of the row)
                 // The 2 * MT fragment halves of the step are read LDS_AHEAD halves before their MFMAs: one half ahead (what the
@@ -565,6 +561,8 @@ __global__ __launch_bounds__(256, (MT * NT <= 32 && sizeof(T) == 2) ? 2 : 1) voi
                     for (int j = 0; j < NT; ++j) acc[t >> 1][j] = F::mma_half(a[s][j], t & 1, hq[t], acc[t >> 1][j]);
                     __builtin_amdgcn_sched_group_barrier(0x008, NT * F::HALF_MFMAS, 0);
                 }
+                tap = ntap;
+                c = nc;
             }
         }
         if (per_phase % PF) {  // an odd number of steps: the chunk in flight sits in the other half of the ring
