@@ -402,37 +402,51 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(const T* __restrict__ W,
     WFragPtr<T> wrow[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) wrow[j] = WFragPtr<T>(W, nb + (4 * j + wave) * 16, K, lane, wpk);
+    // (weight chunks past the end of the K walk are clamped to the last one, not branched around: with a branch between the loads
+    // and their use the compiler cannot count the loads in flight, and every wait becomes a wait for all of them)
 #pragma unroll
-    for (int s = 0; s < PF - 1; ++s)
-        if (s < nC) {
+    for (int s = 0; s < PF - 1; ++s) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) a[s][j].load(wrow[j].chunk(s), wrow[j].hs);
-        }
+        for (int j = 0; j < NT; ++j) a[s][j].load(wrow[j].chunk(min(s, nC - 1)), wrow[j].hs);
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's part of the tile has landed before it signals the barrier
     __syncthreads();
+    // The fragment halves ("pieces": 16 bytes per lane, NT MFMAs each) go through a ring of four, read LDS_AHEAD pieces before their
+    // MFMAs and across step boundaries; (tap, c) of a step are counted along instead of divided out.
+    constexpr int PPS = 2 * MT, LDS_AHEAD = 3;  // pieces per step
+    static_assert(PPS % 4 == 0, "ring of four pieces");
+    auto row_slot = [&](int tap, int c) {
+        const int vb = (c * F::CHUNK + g * F::EPL) / VPE;  // first of the two 16-byte vectors of this lane's fragment
+        return (r + tap * dil) * vpr + tile_pcol(r + tap * dil, vb, vpr);  // (16 rows further: the same slot of the row)
+    };
+    int tap = 0, c = 0, xr = row_slot(0, 0);
+    uint4 hq[4];
+#pragma unroll
+    for (int pp = 0; pp < LDS_AHEAD; ++pp) hq[pp] = tile[(16 * (pp >> 1) * vpr + xr) ^ (pp & 1)];
     for (int q0 = 0; q0 < nC; q0 += PF) {
 #pragma unroll
         for (int s = 0; s < PF; ++s) {
             const int q = q0 + s;
-            if (q + PF - 1 < nC) {
+            if (q >= nC) continue;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) a[(s + PF - 1) % PF][j].load(wrow[j].chunk(q + PF - 1), wrow[j].hs);
+            for (int j = 0; j < NT; ++j) a[(s + PF - 1) % PF][j].load(wrow[j].chunk(min(q + PF - 1, nC - 1)), wrow[j].hs);
+            __builtin_amdgcn_sched_group_barrier(0x020, 2 * NT, 0);
+            int ntap = tap, nc = c + 1;
+            if (nc == cpt) { nc = 0; ++ntap; }
+            if (q + 1 >= nC) { ntap = tap; nc = c; }  // (the last step reads its own first pieces again)
+            const int xn = row_slot(ntap, nc);
+#pragma unroll
+            for (int pp = 0; pp < PPS; ++pp) {
+                const int np = pp + LDS_AHEAD;
+                hq[np % 4] = np < PPS ? tile[(16 * (np >> 1) * vpr + xr) ^ (np & 1)] : tile[(16 * ((np - PPS) >> 1) * vpr + xn) ^ (np & 1)];
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[pp >> 1][j] = F::mma_half(a[s][j], pp & 1, hq[pp % 4], acc[pp >> 1][j]);
+                __builtin_amdgcn_sched_group_barrier(0x008, NT * F::HALF_MFMAS, 0);
             }
-            if (q < nC) {
-                const int tap = q / cpt, c = q - tap * cpt;
-                const int vb = (c * F::CHUNK + g * F::EPL) / VPE;  // first of the two 16-byte vectors of this lane's fragment
-                const int xr = (r + tap * dil) * vpr + tile_pcol(r + tap * dil, vb, vpr);  // (16 rows further: the same slot of the row)
-#pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    const int x0 = 16 * i * vpr + xr;
-                    const uint4 h0 = tile[x0], h1 = tile[x0 ^ 1];
-                    F b;
-                    __builtin_memcpy(&b, &h0, 16);
-                    __builtin_memcpy((char*)&b + 16, &h1, 16);
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = F::mma(a[s][j], b, acc[i][j]);
-                }
-            }
+            tap = ntap;
+            c = nc;
+            xr = xn;
         }
     }
     // Epilogue through LDS: the accumulators (a lane holds 4 columns of one row, 16 rows per wave) are transposed so that
