@@ -105,6 +105,20 @@ def test_units_reading_the_f32_stream_change_nothing():
     assert digests[0] == digests[1]
 
 
+def test_the_f32_stream_epilogue_pass_changes_nothing():
+    """The conv kernels' epilogue pass for the vocoder's usual tail (bias, f32 residual, f32 stream and / or SnakeBeta copy) makes
+    the same values and the same stores as the general tail it stands in for: the waveforms are equal bit for bit."""
+    for dtype in ("bf16", "f32"):
+        digests = []
+        for env in ({}, {"QTTS_EPI_STREAM": "0"}):
+            e = dict(os.environ, **env)
+            r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + UNIT_SCRIPT.replace('dtype="bf16"', 'dtype="%s"' % dtype)], env=e,
+                               capture_output=True, text=True, timeout=280)
+            assert r.returncode == 0 and "wav " in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+            digests.append(r.stdout.split("wav ")[1].split()[0])
+        assert digests[0] == digests[1], dtype
+
+
 def test_k_split_row_tiles_change_nothing():
     """Two 16-row token tiles per k_split block (the choice with several decode streams in flight) add the same products in
     the same order as one tile per block: sampled bf16 codes of a 20-row batch are identical."""
