@@ -605,7 +605,9 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
     // zero rows per strip.  `xin` is the activated input of the block's transposed conv: Bf for the first block,
     // afterwards the previous block's A viewed from its first valid row.
     const char* xin = (const char*)w.Bf.p;
-    bool last_narrow = false;
+    bool last_narrow = false, final_done = false;
+    // QTTS_FINAL_FUSED=0: the output conv as a kernel of its own after a narrow last block, too
+    static const bool final_fused = !(getenv("QTTS_FINAL_FUSED") && atoi(getenv("QTTS_FINAL_FUSED")) == 0);
     for (int b = 0; b < nb; ++b) {
         const CodecState::Block& blk = s.blocks[(size_t)b];
         const int si = nup + b, so = si + 1;
@@ -652,6 +654,15 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
                     e.out2 = w.A.p;
                     e.out2_lo = b + 1 < SPLIT_BLOCKS ? lo : 0;
                 }
+                // the very last unit of a narrow last block takes the output conv along: its activated copy never leaves the CU
+                Unit96Final fin{};
+                const bool with_final = nar && u == 2 && b + 1 == nb && final_fused;
+                if (with_final) {
+                    fin.w = s.final_wn.as<float>(); fin.bias = s.final_b; fin.wav = w.wav.as<float>(); fin.wav_stride = g.wav_max;
+                    e.out2 = nullptr;
+                    e.out2_lo = 0;
+                    final_done = true;
+                }
                 Prof pr{};
                 if (profiling) {
                     pr = Prof{nullptr, nullptr, Mout, CPo, un.c1.K + un.c2.K, un.c1.taps + 1, un.c1.dil};
@@ -660,7 +671,7 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
                     QTTS_HIP(hipEventRecord(pr.a, st));
                 }
                 const bool ok = nar ? launch_conv_unit96(st, un.w1n.p, un.w2n.p, un.c1.dil, un.c1.bias.as<float>(), un.a2.a.as<float>(), un.a2.den.as<float>(), e,
-                                                         rin + (size_t)(Pn - 6 * un.c1.dil) * CW, un.a1.a.as<float>(), un.a1.den.as<float>())
+                                                         rin + (size_t)(Pn - 6 * un.c1.dil) * CW, un.a1.a.as<float>(), un.a1.den.as<float>(), with_final ? &fin : nullptr)
                                     : launch_conv_unit(st, dt, un.c1.wm(), un.c2.wm(), nullptr, CPo, un.c1.taps, un.c1.dil, un.c1.bias.as<float>(),
                                                        un.a2.a.as<float>(), un.a2.den.as<float>(), e, rin + (size_t)(Pn - 6 * un.c1.dil) * CPo,
                                                        un.a1.a.as<float>(), un.a1.den.as<float>());
@@ -741,8 +752,9 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
     }
     // ================= final conv (C -> 1, k = 7) + clamp =================
     const int last = nstage - 1;
-    launch_final_conv(st, dt, w.A.p, last_narrow ? s.final_wn.as<float>() : s.final_w.as<float>(), s.final_b, d_len(last), U, g.Tmax[(size_t)last],
-                      S[(size_t)last], P[(size_t)last], last_narrow ? 96 : s.final_CP, w.wav.as<float>(), g.wav_max);
+    if (!final_done)
+        launch_final_conv(st, dt, w.A.p, last_narrow ? s.final_wn.as<float>() : s.final_w.as<float>(), s.final_b, d_len(last), U, g.Tmax[(size_t)last],
+                          S[(size_t)last], P[(size_t)last], last_narrow ? 96 : s.final_CP, w.wav.as<float>(), g.wav_max);
     QTTS_HIP(hipEventRecord(ev1, st));
     const long up_total = c.total_upsample();
     for (int u = 0; u < U; ++u) {

@@ -1344,12 +1344,17 @@ bool launch_conv_unit(hipStream_t st, int dtype, WMat W1m, WMat W2m, const void*
 // a swizzle, whatever the tap offset (at 13 pieces a third of the groups took two cycles).  Otherwise the persistent scheme of
 // conv_unit_f32_kernel: halo reused inside LDS, own rows read once in the epilogue's thread layout (192 of the 256 threads: 24
 // float4 per row), residual in registers, unrolled K walk with immediate LDS offsets.
-template <int DIL, int PF, int BPC, bool PREFETCH>
+// FIN: the unit is the decoder's last one and the output conv (96 -> 1, seven taps, causal, clamp to [-1, 1];
+// decoder/v2.rs:238-246) runs on its activated output inside the kernel: the SnakeBeta copy goes to an LDS tile of 64 + 6 rows
+// instead of to memory (its first six rows are the previous tile's last six; a workgroup starts one tile early, without storing,
+// to have them for its first tile; rows without output are zeros, which is the causal padding in front of every strip), four
+// threads per sample add up the 7 x 96 products, and only the waveform leaves the kernel.
+template <int DIL, int PF, int BPC, bool PREFETCH, bool FIN = false>
 __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __restrict__ W1, const uint4* __restrict__ W2,
                                                                const float* __restrict__ bias1, const float* __restrict__ alpha2,
                                                                const float* __restrict__ den2, int tiles_per_block, ConvEpi e,
                                                                const float* __restrict__ Xf, const float* __restrict__ alpha1,
-                                                               const float* __restrict__ den1) {
+                                                               const float* __restrict__ den1, Unit96Final fin) {
     using T = bf16_t;
     extern __shared__ uint4 tile[];
     constexpr int C = 96, RT = 64, HALO = 6 * DIL, ROWS_T = RT + HALO, PITCH = 14;  // pieces per LDS row
@@ -1361,6 +1366,15 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
     const long total = (e.M + RT - 1) / RT;
     const long t0 = (long)blockIdx.x * tiles_per_block, t1 = t0 + tiles_per_block < total ? t0 + tiles_per_block : total;
     if (t0 >= total) return;
+    const long ts = (FIN && t0 > 0) ? t0 - 1 : t0;  // first tile walked
+    constexpr int YP = 13;                           // pieces per row of the activated output tile (12 + 1: rows 4 banks apart)
+    __shared__ uint4 ytile[FIN ? (RT + 6) * YP : 1];
+    __shared__ float fw[FIN ? 7 * C : 1];
+    __shared__ long woff[FIN ? 2 : 1][FIN ? RT : 1];  // waveform element of every tile row (< 0: none)
+    if constexpr (FIN) {
+        for (int c = threadIdx.x; c < 7 * C; c += 256) fw[c] = fin.w[c];
+        for (int c = threadIdx.x; c < 6 * YP; c += 256) ytile[c] = make_uint4(0u, 0u, 0u, 0u);
+    }
     uint4* htile = tile + tile_slots;
     float* otile = reinterpret_cast<float*>(htile);
     __shared__ int row_ok[2][RT];
@@ -1392,17 +1406,17 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
         *reinterpret_cast<uint2*>(reinterpret_cast<char*>(base + row * PITCH) + col * 2) =
             make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
     };
-    rows_load(Xf + (t0 * RT + HALO) * C, res);
+    rows_load(Xf + (ts * RT + HALO) * C, res);
     __syncthreads();
     for (int idx = threadIdx.x; idx < HALO * 24; idx += 256) {  // the first tile's halo comes from memory
         const int row = idx / 24, col = 4 * (idx - row * 24);
-        const float4 x = *reinterpret_cast<const float4*>(Xf + (t0 * RT + row) * C + col);
+        const float4 x = *reinterpret_cast<const float4*>(Xf + (ts * RT + row) * C + col);
         const float xv[4] = {x.x, x.y, x.z, x.w};
         snake4_store(tile, row, col, xv);
     }
     const uint4* lrow = tile + (32 * wr + r) * PITCH + g;   // the lane's piece of its row of every 16-row tile
     const uint4* hrow = htile + (32 * wr + r) * PITCH + g;
-    for (long t = t0; t < t1; ++t) {
+    for (long t = ts; t < t1; ++t) {
         const long m0 = t * RT;
         // parameters and weight addresses re-derived per tile: hoisted out of the loop they would sit in registers across the K walk
         long z = 0;  // (an opaque zero offset, not opaque pointers: see conv_unit_f32_kernel)
@@ -1413,14 +1427,18 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
         if ((int)threadIdx.x < RT) {
             const long m = m0 + threadIdx.x;
             int v = 0;
+            long wo = -1;
             if (m < e.M) {
                 const long u = m / e.S_in;
-                v = (int)(m - u * e.S_in) < e.lens[u];
+                const int tp = (int)(m - u * e.S_in);
+                v = tp < e.lens[u];
+                if (FIN && v && t >= t0) wo = u * fin.wav_stride + tp;
             }
             ok[threadIdx.x] = v;
+            if constexpr (FIN) woff[t & 1][threadIdx.x] = wo;
         }
         if constexpr (!PREFETCH) {
-            if (t > t0) rows_load(Xf + (m0 + HALO) * C, res);
+            if (t > ts) rows_load(Xf + (m0 + HALO) * C, res);
         }
         const uint4* w1w = W1l + (size_t)(3 * wc) * STEPS * 64 + lane;  // column tile j, step s: + (j * STEPS + s) * 64
         bf16x8_t a[PF][NT];
@@ -1525,7 +1543,7 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
             const int col = 4 * c4;
             float b2[4], al[4] = {0.f, 0.f, 0.f, 0.f}, dn[4] = {0.f, 0.f, 0.f, 0.f};
             ld4(bias2l + col, b2);
-            if (e.out2) {
+            if (e.out2 || FIN) {
                 ld4(alnl + col, al);
                 ld4(dnnl + col, dn);
             }
@@ -1539,7 +1557,7 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
                     asm volatile("" : "+v"(res[k][q]));
                     if constexpr (PREFETCH) asm volatile("" : "+v"(resn[k][q]));
                 }
-            if (e.out2) {
+            if (e.out2 || FIN) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) snake_prep<T>(al[q], dn[q]);
             }
@@ -1548,6 +1566,12 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
 #pragma unroll
             for (int k = 0; k < IT; ++k) {
                 const int row = k * 8 + r0;
+                if constexpr (FIN) {
+                    if (!ok[row]) {
+                        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ytile + (6 + row) * YP) + col * 2) = make_uint2(0u, 0u);
+                        continue;
+                    }
+                }
                 if (!ok[row]) continue;
                 const float4 a4 = *reinterpret_cast<const float4*>(otile + row * OP + col);
                 // (the sum replaces the residual in its registers: every row's store then reads registers of its own, and the
@@ -1556,6 +1580,13 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
                 v[0] = a4.x + b2[0] + v[0]; v[1] = a4.y + b2[1] + v[1]; v[2] = a4.z + b2[2] + v[2]; v[3] = a4.w + b2[3] + v[3];
                 const long off = obase + (long)k * 8 * C;
                 if (e.out_f32) *reinterpret_cast<float4*>(e.out_f32 + off) = make_float4(v[0], v[1], v[2], v[3]);
+                if constexpr (FIN) {
+                    u16 h[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) h[q] = f32_to_bf16_bits(snake_apply<T>(v[q], al[q], dn[q]));
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(ytile + (6 + row) * YP) + col * 2) =
+                        make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+                }
                 if (e.out2) {
                     float y[4];
                     u16 h[4];
@@ -1576,6 +1607,32 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
             }
           }
         }
+        if constexpr (FIN) {
+            __syncthreads();  // the tile's activated rows are in ytile behind the six carried over
+            {
+                const int sm = threadIdx.x >> 2, part = threadIdx.x & 3;  // sample, quarter of the channels
+                float acc = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 7; ++kk) {
+                    const bf16_t* yr = reinterpret_cast<const bf16_t*>(ytile + (sm + kk) * YP) + part * 24;
+                    const float* wr = fw + kk * C + part * 24;
+#pragma unroll
+                    for (int c8 = 0; c8 < 3; ++c8) {
+                        float yv[8], wv[8];
+                        load8(yr + 8 * c8, yv);
+                        load8(wr + 8 * c8, wv);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc += yv[q] * wv[q];
+                    }
+                }
+                acc += dpp_move<0xB1>(acc);  // quad_perm [1,0,3,2]
+                acc += dpp_move<0x4E>(acc);  // quad_perm [2,3,0,1]
+                const long wo = woff[t & 1][sm];
+                if (part == 0 && wo >= 0) fin.wav[wo] = fminf(1.0f, fmaxf(-1.0f, acc + fin.bias));
+            }
+            __syncthreads();  // every sample has read its rows: the last six become the next tile's first six
+            if ((int)threadIdx.x < 6 * YP) ytile[threadIdx.x] = ytile[RT * YP + threadIdx.x];
+        }
         if constexpr (PREFETCH) {
 #pragma unroll
             for (int k = 0; k < IT; ++k)
@@ -1588,28 +1645,30 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
 namespace {
 template <int DIL, int PF, int BPC, bool PREFETCH>
 bool launch_unit96_cfg(hipStream_t st, const void* W1, const void* W2, const float* bias1, const float* alpha2, const float* den2, const ConvEpi& e,
-                       const float* Xf, const float* alpha1, const float* den1) {
+                       const float* Xf, const float* alpha1, const float* den1, const Unit96Final* fin) {
     constexpr int RT = 64, HALO = 6 * DIL, PITCH = 14;
     constexpr size_t in_b = (size_t)((RT + HALO) * PITCH + 63) / 64 * 64 * 16;
     constexpr size_t second = (size_t)RT * PITCH * 16, staging = (size_t)RT * (96 + 4) * 4;
     constexpr size_t lds = in_b + (second > staging ? second : staging);
-    static_assert(lds * BPC <= (size_t)156 * 1024, "unit tiles of the resident workgroups exceed the LDS of a CU");
+    static_assert((lds + 20 * 1024) * BPC <= (size_t)156 * 1024, "unit tiles of the resident workgroups exceed the LDS of a CU");
     const long total = (e.M + RT - 1) / RT;
     if ((long)RT + HALO + 8 > CONV_HALO_SLACK || total > 0x7fffffffL) return false;
     const long blocks = std::min<long>(total, (long)BPC * 256);
     const int tpb = (int)((total + blocks - 1) / blocks);
     const unsigned grid = (unsigned)((total + tpb - 1) / tpb);
-    auto* fn = conv_unit96_kernel<DIL, PF, BPC, PREFETCH>;
-    QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_CEILING));
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, st, (const uint4*)W1, (const uint4*)W2, bias1, alpha2, den2, tpb, e, Xf, alpha1, den1);
+    auto* fn = fin ? conv_unit96_kernel<DIL, PF, BPC, PREFETCH, true> : conv_unit96_kernel<DIL, PF, BPC, PREFETCH, false>;
+    // (the kernel with the output conv holds 20 KB of static LDS beside the dynamic tiles)
+    QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, fin ? LDS_CEILING - 24 * 1024 : LDS_CEILING));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, st, (const uint4*)W1, (const uint4*)W2, bias1, alpha2, den2, tpb, e, Xf, alpha1, den1,
+                       fin ? *fin : Unit96Final{});
     return true;
 }
 // Measured (13.7 M rows per launch, ms per unit): two workgroups per CU with prefetch 4.15 / 4.22 / 4.13 for dilations 1 / 3 / 9,
 // three per CU without prefetch 4.12 / 4.29 / 4.04; the padded 128-channel unit takes 5.2 / 5.4 / 5.4 for the same rows.
 template <int DIL>
 bool launch_unit96_dil(hipStream_t st, const void* W1, const void* W2, const float* bias1, const float* alpha2, const float* den2, const ConvEpi& e,
-                       const float* Xf, const float* alpha1, const float* den1) {
-    return launch_unit96_cfg<DIL, 4, 2, true>(st, W1, W2, bias1, alpha2, den2, e, Xf, alpha1, den1);
+                       const float* Xf, const float* alpha1, const float* den1, const Unit96Final* fin) {
+    return launch_unit96_cfg<DIL, 4, 2, true>(st, W1, W2, bias1, alpha2, den2, e, Xf, alpha1, den1, fin);
 }
 }  // namespace
 
@@ -1630,14 +1689,24 @@ void conv_unit96_pack(const float* w, int taps, uint16_t* out, uint16_t (*to_bf1
 
 // One residual unit at 96 unpadded channels on the f32 stream (bf16 matrix cores): e.N = e.Cout = e.ld_out = 96, e.resid_f32 = the
 // input stream, Xf = that stream shifted to the tile's first halo row; W1 / W2 from conv_unit96_pack.  False: shape not covered.
+// fin: the unit is the decoder's last and the output conv follows inside the kernel (e.out2 and e.out_f32 null, e.alpha_exp /
+// e.beta_den the output conv's input activation; the waveform of strip u starts at fin->wav + u * fin->wav_stride).
 bool launch_conv_unit96(hipStream_t st, const void* W1, const void* W2, int dil, const float* bias1, const float* alpha2, const float* den2,
-                        const ConvEpi& e, const float* Xf, const float* alpha1, const float* den1) {
+                        const ConvEpi& e, const float* Xf, const float* alpha1, const float* den1, const Unit96Final* fin) {
     QTTS_CHECK(W1 && W2 && Xf && bias1 && alpha2 && den2 && alpha1 && den1 && e.lens && e.M >= 1 && e.S_in >= 1, ERR_BAD_ARG, "conv_unit96: null argument");
-    if (!unit_f32_epilogue(e, 96) || e.N != 96 || (const void*)e.resid_f32 == (const void*)e.out_f32 || e.Cvalid != 0) return false;
+    if (fin) {
+        QTTS_CHECK(fin->w && fin->wav && !e.out2 && !e.out_f32 && e.alpha_exp && e.beta_den, ERR_BAD_ARG, "conv_unit96: bad output conv description");
+        ConvEpi t = e;
+        t.out2 = const_cast<float*>(Xf);  // (any non-null pointer: the shape check below wants an output)
+        if (!unit_f32_epilogue(t, 96)) return false;
+    } else if (!unit_f32_epilogue(e, 96)) {
+        return false;
+    }
+    if (e.N != 96 || (const void*)e.resid_f32 == (const void*)e.out_f32 || e.Cvalid != 0) return false;
     if (Xf != e.resid_f32 + ((long)e.P_out - 6L * dil) * 96) return false;
-    if (dil == 1) return launch_unit96_dil<1>(st, W1, W2, bias1, alpha2, den2, e, Xf, alpha1, den1);
-    if (dil == 3) return launch_unit96_dil<3>(st, W1, W2, bias1, alpha2, den2, e, Xf, alpha1, den1);
-    if (dil == 9) return launch_unit96_dil<9>(st, W1, W2, bias1, alpha2, den2, e, Xf, alpha1, den1);
+    if (dil == 1) return launch_unit96_dil<1>(st, W1, W2, bias1, alpha2, den2, e, Xf, alpha1, den1, fin);
+    if (dil == 3) return launch_unit96_dil<3>(st, W1, W2, bias1, alpha2, den2, e, Xf, alpha1, den1, fin);
+    if (dil == 9) return launch_unit96_dil<9>(st, W1, W2, bias1, alpha2, den2, e, Xf, alpha1, den1, fin);
     return false;
 }
 

@@ -295,8 +295,15 @@ bool launch_conv_halo(hipStream_t st, int dtype, WMat W, const void* X, int K, i
 bool conv_unit_supported(int dtype, int C, int taps, int dil);
 // The fused unit at 96 channels without padding (k_conv.hip): weight layout and launch
 void conv_unit96_pack(const float* w, int taps, uint16_t* out, uint16_t (*to_bf16)(float));
+// the decoder's output conv (96 -> 1, seven taps, clamp) when it runs inside the last unit's kernel
+struct Unit96Final {
+    const float* w = nullptr;  // [7][96]
+    float bias = 0.f;
+    float* wav = nullptr;      // strip u's samples start at wav + u * wav_stride
+    long wav_stride = 0;
+};
 bool launch_conv_unit96(hipStream_t st, const void* W1, const void* W2, int dil, const float* bias1, const float* alpha2, const float* den2,
-                        const ConvEpi& e, const float* Xf, const float* alpha1, const float* den1);
+                        const ConvEpi& e, const float* Xf, const float* alpha1, const float* den1, const Unit96Final* fin = nullptr);
 // Xf (bf16 runs, X null): the unit makes its activated input tile itself from the f32 stream Xf (same addressing as X) with the
 // input activation (alpha1, den1) - no activated copy is read, and the producer need not write one.
 bool launch_conv_unit(hipStream_t st, int dtype, WMat W1, WMat W2, const void* X, int C, int taps, int dil, const float* bias1,

@@ -4,6 +4,8 @@ import os
 import subprocess
 import sys
 
+import numpy as np
+
 import pytest
 
 from conftest import ROOT
@@ -117,6 +119,42 @@ def test_the_f32_stream_epilogue_pass_changes_nothing():
             assert r.returncode == 0 and "wav " in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
             digests.append(r.stdout.split("wav ")[1].split()[0])
         assert digests[0] == digests[1], dtype
+
+
+FINAL_SCRIPT = r"""
+import sys, os
+import numpy as np
+sys.path.insert(0, ROOT)
+import torch
+from qwen3_tts_rs_amd import Model, LoaderConfig, synth
+cfg, ccfg, tmpl = synth.shape_set("S06")
+m = Model(cfg, ccfg, LoaderConfig(dtype="bf16"))
+for k, t in synth.iter_weights_torch(synth.codec_keys(ccfg), 20261111, "cuda:0", True):
+    m.load_tensor(k, t)
+m.finalize()
+codes = np.random.default_rng(5).integers(0, 2048, (3, 70, 16)).astype(np.uint32)
+wavs = m.decode_codes(codes, [70, 41, 9])
+m.close()
+np.save(sys.argv[1], np.concatenate(wavs))
+print("saved", sum(len(w) for w in wavs))
+"""
+
+
+def test_output_conv_inside_the_last_unit_agrees_with_the_separate_kernel(tmp_path):
+    """Reference-default vocoder in bf16: the output conv computed inside the last 96-channel unit's kernel (from the activated rows
+    in LDS, rounded to bf16 as the stored copy would be) against the separate kernel reading that copy from memory.  The same
+    products summed in another order: equal to f32 rounding, ragged strips and the strips' first samples included."""
+    out = []
+    for tag, env in (("fused", {}), ("separate", {"QTTS_FINAL_FUSED": "0"})):
+        path = str(tmp_path / (tag + ".npy"))
+        r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + FINAL_SCRIPT, path], env=dict(os.environ, **env), capture_output=True,
+                           text=True, timeout=280)
+        assert r.returncode == 0 and "saved " in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+        out.append(np.load(path))
+    a, b = out
+    assert a.shape == b.shape and np.isfinite(a).all()
+    err = float(np.abs(a.astype(np.float64) - b).max())
+    assert err <= 2e-6, err   # samples are in [-1, 1]: a few f32 ulps of the 672-term sums
 
 
 def test_k_split_row_tiles_change_nothing():
