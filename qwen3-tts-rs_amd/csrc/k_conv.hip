@@ -12,6 +12,10 @@
 #include <algorithm>
 #include <cstdlib>
 
+#ifndef QTTS_W_STEP
+#define QTTS_W_STEP(s) (s)  // (development probes redefine it to make every step read the same weight fragments)
+#endif
+
 namespace qtts {
 
 namespace {
@@ -1418,6 +1422,8 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
     const uint4* hrow = htile + (32 * wr + r) * PITCH + g;
     for (long t = ts; t < t1; ++t) {
         const long m0 = t * RT;
+        const bool mark = t == ts + 3;  // (time marks of a tile in the steady state: development probe builds only)
+        if (mark) QTTS_TS(0);
         // parameters and weight addresses re-derived per tile: hoisted out of the loop they would sit in registers across the K walk
         long z = 0;  // (an opaque zero offset, not opaque pointers: see conv_unit_f32_kernel)
         asm volatile("" : "+s"(z));
@@ -1457,6 +1463,7 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         __syncthreads();
+        if (mark) QTTS_TS(1);
         // The K walk step by step, every step a scheduling region of its own: its weight loads for PF - 1 steps ahead, its LDS
         // reads for two steps ahead, then its MFMAs.  Without the region boundaries the scheduler sinks loads and reads next to
         // their uses, and every MFMA group then starts with a full LDS round trip.
@@ -1474,7 +1481,7 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
             for (int s = 0; s < STEPS; ++s) {
                 if (s + PF - 1 < STEPS) {
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) a[(s + PF - 1) % PF][j] = __builtin_bit_cast(bf16x8_t, w1w[(j * STEPS + s + PF - 1) * 64]);
+                    for (int j = 0; j < NT; ++j) a[(s + PF - 1) % PF][j] = __builtin_bit_cast(bf16x8_t, w1w[(j * STEPS + QTTS_W_STEP(s + PF - 1)) * 64]);
                 }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
@@ -1486,6 +1493,7 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (mark) QTTS_TS(2);
         // weights of the 1x1 conv: in flight while the tail of the 7-tap conv is computed
         bf16x8_t a2[3][NT];
 #pragma unroll
@@ -1517,6 +1525,7 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
             }
         }
         __syncthreads();  // second tile complete; every wave is past its last read of the input tile
+        if (mark) QTTS_TS(3);
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
@@ -1525,6 +1534,7 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[ks][j], b, acc[i][j], 0, 0, 0);
             }
+        if (mark) QTTS_TS(4);
         // the next tile's halo: rows [RT, RT + HALO) move to the front
         if (t + 1 < t1) {
             for (int sidx = threadIdx.x; sidx < HALO * PITCH; sidx += 256) tile[sidx] = tile[RT * PITCH + sidx];
@@ -1536,6 +1546,7 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
             for (int j = 0; j < NT; ++j)
                 *reinterpret_cast<f32x4_t*>(otile + (32 * wr + 16 * i + r) * OP + (3 * wc + j) * 16 + 4 * g) = acc[i][j];
         __syncthreads();
+        if (mark) QTTS_TS(5);
         // The residual rows (and the next tile's) have been in flight since before the K walk.  One wait here, and the values
         // are passed through an empty asm statement: behind the conditional stores below the compiler can no longer count, and
         // would wait for everything in flight - the previous row's stores included - before every row.
@@ -1607,6 +1618,7 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
             }
           }
         }
+        if (mark) QTTS_TS(6);
         if constexpr (FIN) {
             __syncthreads();  // the tile's activated rows are in ytile behind the six carried over
             {
