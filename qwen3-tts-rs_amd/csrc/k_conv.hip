@@ -926,11 +926,24 @@ __global__ __launch_bounds__(256, BPC) void conv_unit_f32_kernel(const bf16_t* _
     float* otile = reinterpret_cast<float*>(htile);
     __shared__ int row_ok[2][RT];
     __shared__ float sn1[2 * C];
+    // per-channel parameters of the tail and of the epilogue as snake_prep leaves them: read from memory once per workgroup instead
+    // of once per tile, where each read was a round trip in front of the tail and of the epilogue
+    __shared__ float prm[6 * C];
     for (int c = threadIdx.x; c < C; c += 256) {
         float al = alpha1[c], dn = den1[c];
         snake_prep<T>(al, dn);
         sn1[c] = al;
         sn1[C + c] = dn;
+        prm[c] = bias1[c];
+        al = alpha2[c]; dn = den2[c];
+        snake_prep<T>(al, dn);
+        prm[C + c] = al;
+        prm[2 * C + c] = dn;
+        prm[3 * C + c] = e.bias[c];
+        al = 0.f; dn = 0.f;
+        if (e.out2) { al = e.alpha_exp[c]; dn = e.beta_den[c]; snake_prep<T>(al, dn); }
+        prm[4 * C + c] = al;
+        prm[5 * C + c] = dn;
     }
     float res[NP][IT][4], resn[PREFETCH ? NP : 1][PREFETCH ? IT : 1][4];
     unit_rows_load<RT, GPR, NP>(Xf + (t0 * RT + HALO) * C, C, res);
@@ -952,7 +965,6 @@ __global__ __launch_bounds__(256, BPC) void conv_unit_f32_kernel(const bf16_t* _
         long z = 0;
         asm volatile("" : "+s"(z));
         const bf16_t *W1l = W1 + z, *W2l = W2 + z;
-        const float *bias1l = bias1 + z, *alpha2l = alpha2 + z, *den2l = den2 + z, *bias2l = e.bias + z, *alnl = e.alpha_exp + z, *dnnl = e.beta_den + z;
         WFragPtr<T> wrow[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) wrow[j] = WFragPtr<T>(W1l, (4 * j + wave_s) * 16, K, lane, wpk);
@@ -1032,11 +1044,9 @@ __global__ __launch_bounds__(256, BPC) void conv_unit_f32_kernel(const bf16_t* _
         for (int j = 0; j < NT; ++j) {
             const int n = (4 * j + wave) * 16 + 4 * g;
             float bs[4], al[4], dn[4];
-            ld4(bias1l + n, bs);
-            ld4(alpha2l + n, al);
-            ld4(den2l + n, dn);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) snake_prep<T>(al[q], dn[q]);
+            ld4(prm + n, bs);
+            ld4(prm + C + n, al);
+            ld4(prm + 2 * C + n, dn);
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int row = 16 * i + r;
@@ -1086,14 +1096,10 @@ __global__ __launch_bounds__(256, BPC) void conv_unit_f32_kernel(const bf16_t* _
             __syncthreads();
             const int col = p * CP + 4 * c4;
             if (e.Cvalid && col >= e.Cvalid) continue;  // columns past the layer's real width are padding (the barriers are block-uniform)
-            float b2[4], al[4] = {0.f, 0.f, 0.f, 0.f}, dn[4] = {0.f, 0.f, 0.f, 0.f};
-            ld4(bias2l + col, b2);
-            if (e.out2) {
-                ld4(alnl + col, al);
-                ld4(dnnl + col, dn);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) snake_prep<T>(al[q], dn[q]);
-            }
+            float b2[4], al[4], dn[4];
+            ld4(prm + 3 * C + col, b2);
+            ld4(prm + 4 * C + col, al);
+            ld4(prm + 5 * C + col, dn);
             const long obase = (m0 + r0 + e.P_out) * C + col;
 #pragma unroll
             for (int k = 0; k < IT; ++k) {
@@ -1383,11 +1389,25 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
     float* otile = reinterpret_cast<float*>(htile);
     __shared__ int row_ok[2][RT];
     __shared__ float sn1[2 * C];
+    // per-channel parameters of the tail (bias of the 7-tap conv, its SnakeBeta) and of the epilogue (bias of the 1x1 conv, the
+    // SnakeBeta of the copy for the next layer), as snake_prep leaves them: read from memory once per workgroup instead of once
+    // per tile, where each read was a round trip in front of the tail and of the epilogue
+    __shared__ float prm[6 * C];
     for (int c = threadIdx.x; c < C; c += 256) {
         float al = alpha1[c], dn = den1[c];
         snake_prep<T>(al, dn);
         sn1[c] = al;
         sn1[C + c] = dn;
+        prm[c] = bias1[c];
+        al = alpha2[c]; dn = den2[c];
+        snake_prep<T>(al, dn);
+        prm[C + c] = al;
+        prm[2 * C + c] = dn;
+        prm[3 * C + c] = e.bias[c];
+        al = 0.f; dn = 0.f;
+        if (e.out2 || FIN) { al = e.alpha_exp[c]; dn = e.beta_den[c]; snake_prep<T>(al, dn); }
+        prm[4 * C + c] = al;
+        prm[5 * C + c] = dn;
     }
     const bool rowthr = threadIdx.x < 192;  // the threads that move rows: 24 float4 per row, eight rows per pass
     const int c4 = rowthr ? (int)threadIdx.x % 24 : 0, r0 = rowthr ? (int)threadIdx.x / 24 : 0;
@@ -1428,7 +1448,6 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
         long z = 0;  // (an opaque zero offset, not opaque pointers: see conv_unit_f32_kernel)
         asm volatile("" : "+s"(z));
         const uint4 *W1l = W1 + z, *W2l = W2 + z;
-        const float *bias1l = bias1 + z, *alpha2l = alpha2 + z, *den2l = den2 + z, *bias2l = e.bias + z, *alnl = e.alpha_exp + z, *dnnl = e.beta_den + z;
         int* ok = row_ok[t & 1];
         if ((int)threadIdx.x < RT) {
             const long m = m0 + threadIdx.x;
@@ -1505,11 +1524,9 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
         for (int j = 0; j < NT; ++j) {
             const int n = (3 * wc + j) * 16 + 4 * g;
             float bs[4], al[4], dn[4];
-            ld4(bias1l + n, bs);
-            ld4(alpha2l + n, al);
-            ld4(den2l + n, dn);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) snake_prep<T>(al[q], dn[q]);
+            ld4(prm + n, bs);
+            ld4(prm + C + n, al);
+            ld4(prm + 2 * C + n, dn);
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int row = 32 * wr + 16 * i + r;
@@ -1552,15 +1569,11 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
         // would wait for everything in flight - the previous row's stores included - before every row.
         {
             const int col = 4 * c4;
-            float b2[4], al[4] = {0.f, 0.f, 0.f, 0.f}, dn[4] = {0.f, 0.f, 0.f, 0.f};
-            ld4(bias2l + col, b2);
-            if (e.out2 || FIN) {
-                ld4(alnl + col, al);
-                ld4(dnnl + col, dn);
-            }
+            float b2[4], al[4], dn[4];
+            ld4(prm + 3 * C + col, b2);
+            ld4(prm + 4 * C + col, al);
+            ld4(prm + 5 * C + col, dn);
             __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(b2[q]), "+v"(al[q]), "+v"(dn[q]));
 #pragma unroll
             for (int k = 0; k < IT; ++k)
 #pragma unroll
@@ -1568,10 +1581,6 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
                     asm volatile("" : "+v"(res[k][q]));
                     if constexpr (PREFETCH) asm volatile("" : "+v"(resn[k][q]));
                 }
-            if (e.out2 || FIN) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) snake_prep<T>(al[q], dn[q]);
-            }
           if (rowthr) {
             const long obase = (m0 + r0 + e.P_out) * C + col;
 #pragma unroll
@@ -1662,7 +1671,7 @@ bool launch_unit96_cfg(hipStream_t st, const void* W1, const void* W2, const flo
     constexpr size_t in_b = (size_t)((RT + HALO) * PITCH + 63) / 64 * 64 * 16;
     constexpr size_t second = (size_t)RT * PITCH * 16, staging = (size_t)RT * (96 + 4) * 4;
     constexpr size_t lds = in_b + (second > staging ? second : staging);
-    static_assert((lds + 20 * 1024) * BPC <= (size_t)156 * 1024, "unit tiles of the resident workgroups exceed the LDS of a CU");
+    static_assert((lds + 22 * 1024) * BPC <= (size_t)156 * 1024, "unit tiles of the resident workgroups exceed the LDS of a CU");
     const long total = (e.M + RT - 1) / RT;
     if ((long)RT + HALO + 8 > CONV_HALO_SLACK || total > 0x7fffffffL) return false;
     const long blocks = std::min<long>(total, (long)BPC * 256);
