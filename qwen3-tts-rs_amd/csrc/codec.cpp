@@ -641,7 +641,36 @@ void Decoder::run_group(const uint32_t* d_codes, int T_max, const std::vector<Pi
             QTTS_HIP(hipMemset2DAsync(w.Rf2.p, (size_t)S[(size_t)so] * CW * 4, 0, (size_t)Pn * CW * 4, (size_t)U, st));
             float* rin = w.Rf.as<float>();
             float* rout = w.Rf2.as<float>();
-            for (int u = 0; u < 3; ++u) {
+            // QTTS_UNIT96_PAIR=0: every unit of a narrow block a launch of its own
+            static const bool pair_on = !(getenv("QTTS_UNIT96_PAIR") && atoi(getenv("QTTS_UNIT96_PAIR")) == 0);
+            int u_first = 0;
+            if (nar && pair_on && blk.u[0].c1.dil == 1 && blk.u[1].c1.dil == 3) {
+                // the first two units of a narrow block in one launch: the stream between them stays on the CU
+                const CodecState::Unit &ua = blk.u[0], &ub = blk.u[1];
+                ConvEpi e{};
+                e.M = Mout; e.N = CW; e.r = 1; e.Cout = CW; e.bias = ua.c2.bias.as<float>();
+                e.resid_f32 = rin; e.lens = d_len(so); e.S_in = S[(size_t)so]; e.S_out = S[(size_t)so]; e.P_out = Pn; e.ld_out = CW;
+                e.out_f32 = rout;
+                Prof pr{};
+                if (profiling) {  // (reported as one conv of 16 "taps": two units)
+                    pr = Prof{nullptr, nullptr, Mout, CPo, ua.c1.K + ua.c2.K + ub.c1.K + ub.c2.K, 2 * (ua.c1.taps + 1), 1};
+                    QTTS_HIP(hipEventCreate(&pr.a));
+                    QTTS_HIP(hipEventCreate(&pr.b));
+                    QTTS_HIP(hipEventRecord(pr.a, st));
+                }
+                if (launch_conv_unit96_pair(st, ua.w1n.p, ua.w2n.p, 1, 3, ua.c1.bias.as<float>(), ua.a2.a.as<float>(), ua.a2.den.as<float>(), e,
+                                            rin + (size_t)(Pn - 6) * CW, ua.a1.a.as<float>(), ua.a1.den.as<float>(), ub.w1n.p, ub.w2n.p,
+                                            ub.c1.bias.as<float>(), ub.a2.a.as<float>(), ub.a2.den.as<float>(), ub.c2.bias.as<float>(),
+                                            ub.a1.a.as<float>(), ub.a1.den.as<float>())) {
+                    std::swap(rin, rout);
+                    u_first = 2;
+                    if (profiling) {
+                        QTTS_HIP(hipEventRecord(pr.b, st));
+                        prof.push_back(pr);
+                    }
+                }
+            }
+            for (int u = u_first; u < 3; ++u) {
                 const CodecState::Unit& un = blk.u[u];
                 ConvEpi e{};
                 e.M = Mout; e.N = CW; e.r = 1; e.Cout = CW; e.bias = un.c2.bias.as<float>();

@@ -1663,6 +1663,267 @@ __global__ __launch_bounds__(256, BPC) void conv_unit96_kernel(const uint4* __re
     }
 }
 
+// TWO consecutive 96-channel units (dilations DA, DB) in one persistent kernel: the first unit's output never goes to memory.  Its
+// f32 values stay in the registers that held its residual and become the second unit's residual; their SnakeBeta copy goes into
+// the second unit's LDS input tile, whose causal halo is, as for the first unit, the tail of the previous tile's rows.  A workgroup
+// starts one tile early without storing (the second unit's halo of 6 DB rows must come from the first unit's output of the rows
+// before the workgroup's own); rows without output pass zeros on, which is the causal padding in front of every strip (at least
+// 6 * 9 such rows precede a strip's first row in the row space).  Every value is computed as by two launches of
+// conv_unit96_kernel: the results are equal bit for bit.
+struct Unit96Second {
+    const uint4 *W1, *W2;                                // conv_unit96_pack layout
+    const float *bias1, *alpha2, *den2, *bias2;          // 7-tap conv bias, its SnakeBeta, 1x1 conv bias
+    const float *alpha1, *den1;                          // the second unit's input activation
+};
+template <int DA, int DB, int PF, int BPC>
+__global__ __launch_bounds__(256, BPC) void conv_unit96x2_kernel(const uint4* __restrict__ W1, const uint4* __restrict__ W2,
+                                                                 const float* __restrict__ bias1, const float* __restrict__ alpha2,
+                                                                 const float* __restrict__ den2, int tiles_per_block, ConvEpi e,
+                                                                 const float* __restrict__ Xf, const float* __restrict__ alpha1,
+                                                                 const float* __restrict__ den1, Unit96Second sb) {
+    using T = bf16_t;
+    extern __shared__ uint4 tile[];
+    constexpr int C = 96, RT = 64, HA = 6 * DA, HB = 6 * DB, PITCH = 14;
+    constexpr int STEPS = 21, NT = 3, MT = 2, OP = C + 4, IT = 8;
+    constexpr int slotsA = ((RT + HA) * PITCH + 63) / 64 * 64, slotsB = ((RT + HB) * PITCH + 63) / 64 * 64;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int wr = wave >> 1, wc = wave & 1;
+    const long total = (e.M + RT - 1) / RT;
+    const long t0 = (long)blockIdx.x * tiles_per_block, t1 = t0 + tiles_per_block < total ? t0 + tiles_per_block : total;
+    if (t0 >= total) return;
+    const long ts = t0 > 0 ? t0 - 1 : t0;  // first tile walked
+    uint4* tileB = tile + slotsA;
+    uint4* htile = tileB + slotsB;
+    float* otile = reinterpret_cast<float*>(htile);
+    __shared__ int row_ok[2][RT];
+    __shared__ float snA[2 * C], snB[2 * C];
+    __shared__ float prm[10 * C];  // unit A: bias1, alpha2', den2', bias2; unit B: the same four; the next layer's alpha', den'
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float al = alpha1[c], dn = den1[c];
+        snake_prep<T>(al, dn);
+        snA[c] = al; snA[C + c] = dn;
+        al = sb.alpha1[c]; dn = sb.den1[c];
+        snake_prep<T>(al, dn);
+        snB[c] = al; snB[C + c] = dn;
+        prm[c] = bias1[c];
+        al = alpha2[c]; dn = den2[c];
+        snake_prep<T>(al, dn);
+        prm[C + c] = al; prm[2 * C + c] = dn;
+        prm[3 * C + c] = e.bias[c];
+        prm[4 * C + c] = sb.bias1[c];
+        al = sb.alpha2[c]; dn = sb.den2[c];
+        snake_prep<T>(al, dn);
+        prm[5 * C + c] = al; prm[6 * C + c] = dn;
+        prm[7 * C + c] = sb.bias2[c];
+        al = 0.f; dn = 0.f;
+        if (e.out2) { al = e.alpha_exp[c]; dn = e.beta_den[c]; snake_prep<T>(al, dn); }
+        prm[8 * C + c] = al; prm[9 * C + c] = dn;
+    }
+    for (int i = threadIdx.x; i < HB * PITCH; i += 256) tileB[i] = make_uint4(0u, 0u, 0u, 0u);  // (only the unstored first tile reads these)
+    const bool rowthr = threadIdx.x < 192;
+    const int c4 = rowthr ? (int)threadIdx.x % 24 : 0, r0 = rowthr ? (int)threadIdx.x / 24 : 0;
+    float res[IT][4], resn[IT][4];
+    auto rows_load = [&](const float* src, float (&dst)[IT][4]) {
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const float4 x = *reinterpret_cast<const float4*>(src + (long)(k * 8 + r0) * C + 4 * c4);
+            dst[k][0] = x.x; dst[k][1] = x.y; dst[k][2] = x.z; dst[k][3] = x.w;
+        }
+    };
+    auto snake4_store = [&](uint4* base, const float* sn, int row, int col, const float (&x)[4]) {
+        const float4 al = *reinterpret_cast<const float4*>(sn + col), dn = *reinterpret_cast<const float4*>(sn + C + col);
+        const float alv[4] = {al.x, al.y, al.z, al.w}, dnv[4] = {dn.x, dn.y, dn.z, dn.w};
+        u16 h[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[q] = f32_to_bf16_bits(snake_apply<T>(x[q], alv[q], dnv[q]));
+        *reinterpret_cast<uint2*>(reinterpret_cast<char*>(base + row * PITCH) + col * 2) =
+            make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    };
+    rows_load(Xf + (ts * RT + HA) * C, res);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < HA * 24; idx += 256) {  // the first tile's halo of the first unit comes from memory
+        const int row = idx / 24, col = 4 * (idx - row * 24);
+        const float4 x = *reinterpret_cast<const float4*>(Xf + (ts * RT + row) * C + col);
+        const float xv[4] = {x.x, x.y, x.z, x.w};
+        snake4_store(tile, snA, row, col, xv);
+    }
+    const uint4* lrowA = tile + (32 * wr + r) * PITCH + g;
+    const uint4* lrowB = tileB + (32 * wr + r) * PITCH + g;
+    const uint4* hrow = htile + (32 * wr + r) * PITCH + g;
+    f32x4_t acc[MT][NT];
+    // one unit's matrix work on an input tile: 7-tap conv, its tail into the second tile, 1x1 conv, accumulators into the staging tile
+    auto unit_core = [&](auto dil_c, const uint4* lrow, uint4* in_tile, const uint4* W1l, const uint4* W2l, const float* pr) {
+        constexpr int DIL = decltype(dil_c)::value;
+        const uint4* w1w = W1l + (size_t)(3 * wc) * STEPS * 64 + lane;
+        bf16x8_t a[PF][NT];
+#pragma unroll
+        for (int s = 0; s < PF - 1; ++s)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) a[s][j] = __builtin_bit_cast(bf16x8_t, w1w[(j * STEPS + s) * 64]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();  // the input tile is complete
+        {
+            constexpr int NPC = STEPS * MT, LDS_AHEAD = 2 * MT;
+            bf16x8_t bq[NPC + LDS_AHEAD];
+            auto frag = [&](int t) {
+                const int s = t / MT, i = t % MT, tap = s / 3, ks = s % 3;
+                return __builtin_bit_cast(bf16x8_t, lrow[(16 * i + tap * DIL) * PITCH + ks * 4]);
+            };
+#pragma unroll
+            for (int t = 0; t < LDS_AHEAD; ++t) bq[t] = frag(t);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                if (s + PF - 1 < STEPS) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) a[(s + PF - 1) % PF][j] = __builtin_bit_cast(bf16x8_t, w1w[(j * STEPS + s + PF - 1) * 64]);
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    if (s * MT + i + LDS_AHEAD < NPC) bq[s * MT + i + LDS_AHEAD] = frag(s * MT + i + LDS_AHEAD);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s % PF][j], bq[s * MT + i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        bf16x8_t a2[3][NT];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) a2[ks][j] = __builtin_bit_cast(bf16x8_t, W2l[((size_t)(3 * wc + j) * 3 + ks) * 64 + lane]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = (3 * wc + j) * 16 + 4 * g;
+            float bs[4], al[4], dn[4];
+            ld4(pr + n, bs);
+            ld4(pr + C + n, al);
+            ld4(pr + 2 * C + n, dn);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int row = 32 * wr + 16 * i + r;
+                u16 h[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float x = bf16_bits_to_f32(f32_to_bf16_bits(acc[i][j][q] + bs[q]));
+                    h[q] = f32_to_bf16_bits(snake_apply<T>(x, al[q], dn[q]));
+                }
+                *reinterpret_cast<uint2*>(reinterpret_cast<char*>(htile + row * PITCH) + n * 2) =
+                    make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+                acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        __syncthreads();  // second tile complete; every wave is past its last read of the input tile
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const bf16x8_t b = __builtin_bit_cast(bf16x8_t, hrow[16 * i * PITCH + ks * 4]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[ks][j], b, acc[i][j], 0, 0, 0);
+            }
+        // the next tile's halo: rows [RT, RT + halo) move to the front
+        for (int sidx = threadIdx.x; sidx < 6 * DIL * PITCH; sidx += 256) in_tile[sidx] = in_tile[RT * PITCH + sidx];
+        __syncthreads();  // every wave is past its reads of the second tile: the f32 staging tile takes its place
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                *reinterpret_cast<f32x4_t*>(otile + (32 * wr + 16 * i + r) * OP + (3 * wc + j) * 16 + 4 * g) = acc[i][j];
+        __syncthreads();
+    };
+    for (long t = ts; t < t1; ++t) {
+        const long m0 = t * RT;
+        long z = 0;  // (an opaque zero offset, not opaque pointers: see conv_unit_f32_kernel)
+        asm volatile("" : "+s"(z));
+        int* ok = row_ok[t & 1];
+        if ((int)threadIdx.x < RT) {
+            const long m = m0 + threadIdx.x;
+            int v = 0;
+            if (m < e.M) {
+                const long u = m / e.S_in;
+                v = (int)(m - u * e.S_in) < e.lens[u];
+            }
+            ok[threadIdx.x] = v;
+        }
+        if (rowthr) {
+#pragma unroll
+            for (int k = 0; k < IT; ++k) snake4_store(tile, snA, HA + k * 8 + r0, 4 * c4, res[k]);
+        }
+        rows_load(Xf + ((t + 1 < t1 ? m0 + RT : m0) + HA) * C, resn);  // (the last tile reads its own rows again)
+        unit_core(std::integral_constant<int, DA>{}, lrowA, tile, W1 + z, W2 + z, prm);
+        // ---- the first unit's epilogue: its sum replaces the residual in registers, its activated copy is the second unit's input
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the residual rows (and the next tile's) have landed, see conv_unit96_kernel
+#pragma unroll
+        for (int k = 0; k < IT; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(res[k][q]), "+v"(resn[k][q]));
+        if (rowthr) {
+            const int col = 4 * c4;
+            float b2[4];
+            ld4(prm + 3 * C + col, b2);
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+                const int row = k * 8 + r0;
+                float (&v)[4] = res[k];
+                if (ok[row]) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(otile + row * OP + col);
+                    v[0] = a4.x + b2[0] + v[0]; v[1] = a4.y + b2[1] + v[1]; v[2] = a4.z + b2[2] + v[2]; v[3] = a4.w + b2[3] + v[3];
+                } else {
+                    v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f;  // SnakeBeta of 0 is 0
+                }
+                snake4_store(tileB, snB, HB + row, col, v);
+            }
+        }
+        unit_core(std::integral_constant<int, DB>{}, lrowB, tileB, sb.W1 + z, sb.W2 + z, prm + 4 * C);
+        // ---- the second unit's epilogue
+        if (rowthr && t >= t0) {
+            const int col = 4 * c4;
+            float b2[4], al[4], dn[4];
+            ld4(prm + 7 * C + col, b2);
+            ld4(prm + 8 * C + col, al);
+            ld4(prm + 9 * C + col, dn);
+            const long obase = (m0 + r0 + e.P_out) * C + col;
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+                const int row = k * 8 + r0;
+                if (!ok[row]) continue;
+                const float4 a4 = *reinterpret_cast<const float4*>(otile + row * OP + col);
+                float (&v)[4] = res[k];
+                v[0] = a4.x + b2[0] + v[0]; v[1] = a4.y + b2[1] + v[1]; v[2] = a4.z + b2[2] + v[2]; v[3] = a4.w + b2[3] + v[3];
+                const long off = obase + (long)k * 8 * C;
+                if (e.out_f32) *reinterpret_cast<float4*>(e.out_f32 + off) = make_float4(v[0], v[1], v[2], v[3]);
+                if (e.out2) {
+                    float y[4];
+                    u16 h[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        y[q] = snake_apply<T>(v[q], al[q], dn[q]);
+                        h[q] = f32_to_bf16_bits(y[q]);
+                    }
+                    T* o = (T*)e.out2 + off;
+                    *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+                    if (e.out2_lo) {
+                        u16 l[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) l[q] = f32_to_bf16_bits(y[q] - bf16_bits_to_f32(h[q]));
+                        *reinterpret_cast<uint2*>(o + e.out2_lo) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < IT; ++k)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) res[k][q] = resn[k][q];
+    }
+}
+
 namespace {
 template <int DIL, int PF, int BPC, bool PREFETCH>
 bool launch_unit96_cfg(hipStream_t st, const void* W1, const void* W2, const float* bias1, const float* alpha2, const float* den2, const ConvEpi& e,
@@ -1692,6 +1953,42 @@ bool launch_unit96_dil(hipStream_t st, const void* W1, const void* W2, const flo
     return launch_unit96_cfg<DIL, 4, 2, true>(st, W1, W2, bias1, alpha2, den2, e, Xf, alpha1, den1, fin);
 }
 }  // namespace
+
+namespace {
+template <int DA, int DB>
+bool launch_unit96x2_cfg(hipStream_t st, const void* W1, const void* W2, const float* bias1, const float* alpha2, const float* den2, const ConvEpi& e,
+                         const float* Xf, const float* alpha1, const float* den1, const Unit96Second& sb) {
+    constexpr int RT = 64, PITCH = 14, BPC = 2;
+    constexpr size_t inA = (size_t)((RT + 6 * DA) * PITCH + 63) / 64 * 64 * 16, inB = (size_t)((RT + 6 * DB) * PITCH + 63) / 64 * 64 * 16;
+    constexpr size_t second = (size_t)RT * PITCH * 16, staging = (size_t)RT * (96 + 4) * 4;
+    constexpr size_t lds = inA + inB + (second > staging ? second : staging);
+    static_assert((lds + 7 * 1024) * BPC <= (size_t)156 * 1024, "unit tiles of the resident workgroups exceed the LDS of a CU");
+    const long total = (e.M + RT - 1) / RT;
+    if ((long)RT + 6 * DB + 8 > CONV_HALO_SLACK || total > 0x7fffffffL) return false;
+    const long blocks = std::min<long>(total, (long)BPC * 256);
+    const int tpb = (int)((total + blocks - 1) / blocks);
+    const unsigned grid = (unsigned)((total + tpb - 1) / tpb);
+    auto* fn = conv_unit96x2_kernel<DA, DB, 4, BPC>;
+    QTTS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_CEILING - 8 * 1024));
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds, st, (const uint4*)W1, (const uint4*)W2, bias1, alpha2, den2, tpb, e, Xf, alpha1, den1, sb);
+    return true;
+}
+}  // namespace
+
+// Two consecutive units (dilations 1 and 3) in one launch: the first unit's arguments as for launch_conv_unit96 (e.bias its 1x1
+// bias, e.resid_f32 / Xf the stream it reads), e's outputs are the pair's; the *b arguments belong to the second unit.  False:
+// not covered.
+bool launch_conv_unit96_pair(hipStream_t st, const void* W1, const void* W2, int dilA, int dilB, const float* bias1, const float* alpha2,
+                             const float* den2, const ConvEpi& e, const float* Xf, const float* alpha1, const float* den1, const void* W1b,
+                             const void* W2b, const float* bias1b, const float* alpha2b, const float* den2b, const float* bias2b,
+                             const float* alpha1b, const float* den1b) {
+    QTTS_CHECK(W1 && W2 && Xf && bias1 && alpha2 && den2 && alpha1 && den1 && W1b && W2b && bias1b && alpha2b && den2b && bias2b && alpha1b && den1b &&
+                   e.lens && e.M >= 1 && e.S_in >= 1, ERR_BAD_ARG, "conv_unit96_pair: null argument");
+    if (!unit_f32_epilogue(e, 96) || e.N != 96 || (const void*)e.resid_f32 == (const void*)e.out_f32 || e.Cvalid != 0) return false;
+    if (Xf != e.resid_f32 + ((long)e.P_out - 6L * dilA) * 96 || dilA != 1 || dilB != 3) return false;
+    Unit96Second sb{(const uint4*)W1b, (const uint4*)W2b, bias1b, alpha2b, den2b, bias2b, alpha1b, den1b};
+    return launch_unit96x2_cfg<1, 3>(st, W1, W2, bias1, alpha2, den2, e, Xf, alpha1, den1, sb);
+}
 
 // Weights of a 96-channel unit in the order conv_unit96_kernel reads them.  w: the conv's f32 weight (96, 96, taps) as the
 // checkpoint holds it; out: 6 column tiles x (taps * 3) steps x 64 lanes x 8 bf16 - lane (r, g) of tile j, step (tap, ks) holds

@@ -304,6 +304,13 @@ struct Unit96Final {
 };
 bool launch_conv_unit96(hipStream_t st, const void* W1, const void* W2, int dil, const float* bias1, const float* alpha2, const float* den2,
                         const ConvEpi& e, const float* Xf, const float* alpha1, const float* den1, const Unit96Final* fin = nullptr);
+// Two consecutive 96-channel units (dilations 1 and 3) in one launch.  The first unit's arguments as for launch_conv_unit96
+// (e.bias = ITS 1x1 bias; e.resid_f32 / Xf = the stream it reads); e's outputs are the PAIR's outputs; the *b arguments are the
+// second unit's weights, biases (bias2b: its 1x1 bias), SnakeBeta of its 7-tap conv and its input activation.
+bool launch_conv_unit96_pair(hipStream_t st, const void* W1, const void* W2, int dilA, int dilB, const float* bias1, const float* alpha2,
+                             const float* den2, const ConvEpi& e, const float* Xf, const float* alpha1, const float* den1, const void* W1b,
+                             const void* W2b, const float* bias1b, const float* alpha2b, const float* den2b, const float* bias2b,
+                             const float* alpha1b, const float* den1b);
 // Xf (bf16 runs, X null): the unit makes its activated input tile itself from the f32 stream Xf (same addressing as X) with the
 // input activation (alpha1, den1) - no activated copy is read, and the producer need not write one.
 bool launch_conv_unit(hipStream_t st, int dtype, WMat W1, WMat W2, const void* X, int C, int taps, int dil, const float* bias1,

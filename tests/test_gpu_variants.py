@@ -157,6 +157,20 @@ def test_output_conv_inside_the_last_unit_agrees_with_the_separate_kernel(tmp_pa
     assert err <= 2e-6, err   # samples are in [-1, 1]: a few f32 ulps of the 672-term sums
 
 
+def test_two_units_in_one_launch_change_nothing(tmp_path):
+    """Reference-default vocoder in bf16: the first two residual units of the 96-channel block in one kernel (the stream between
+    them stays in registers and LDS) against a launch per unit - every value goes through the same arithmetic, so the waveforms
+    are equal bit for bit (ragged strips included: rows without output must pass exact zeros on)."""
+    out = []
+    for tag, env in (("pair", {}), ("single", {"QTTS_UNIT96_PAIR": "0"})):
+        path = str(tmp_path / (tag + ".npy"))
+        r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + FINAL_SCRIPT, path], env=dict(os.environ, **env), capture_output=True,
+                           text=True, timeout=280)
+        assert r.returncode == 0 and "saved " in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+        out.append(np.load(path))
+    assert out[0].shape == out[1].shape and np.array_equal(out[0], out[1])
+
+
 def test_k_split_row_tiles_change_nothing():
     """Two 16-row token tiles per k_split block (the choice with several decode streams in flight) add the same products in
     the same order as one tile per block: sampled bf16 codes of a 20-row batch are identical."""
