@@ -41,5 +41,5 @@ for f in sorted(os.listdir(G)):
         open(f"{P}/{dst}_codec_conv_profile.txt", "w").write(
             f"# {dst} - codec decoder, 64 utterances x 375 frames, bf16, reference-default codec shape: HIP-event time of every conv launch\n"
             "# (QTTS_CODEC_PROFILE=1 REPS=3 python3 tools/dev/dev_codec_prof.py; two groups of utterances per decode; the last repetition is shown).\n"
-            "# taps = 8 rows are fused residual units (7-tap conv + SnakeBeta + 1x1 conv + residual, one launch).\n" + "".join(lines[-62:]))
+            "# taps = 8 rows are fused residual units (7-tap conv + SnakeBeta + 1x1 conv + residual, one launch; the last one of a decode includes the output conv),\n# taps = 16 rows two such units in one launch.\n" + "".join(lines[-62:]))
 print("ok")
