@@ -167,10 +167,11 @@ __device__ __forceinline__ float key_group_sum(float s) {
 // append) happens inside the attention block, so one launch replaces qkv_post + attention.  Valid only when a
 // token's newest key is its own position and no other token of the launch attends to it (decode steps, the code
 // predictor's single-token passes); prefill chunks use the two-kernel path.
-template <typename T, int D, int REP, int NG>
-__global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KVView kv, float scale, T* out, long out_lo) {
+template <typename T, int D, int REP, int NG, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_decode_kernel(QkvPostArgs a, KVView kv, float scale, T* out, long out_lo) {
     constexpr int LPK = D / 8, KPW = 64 / LPK, HALF = D / 2;
-    constexpr int NP = 4 * KPW;  // partial results of a block: one per (wave, lane group)
+    constexpr int NP = NW * KPW;  // partial results of a block: one per (wave, lane group)
+    static_assert(REP * NP <= NW * 64, "the merge needs one thread per (head, partial)");
     __shared__ float po[NP][REP][D];         // unnormalised weighted sums of V
     __shared__ float pm[NP][REP], pl[NP][REP], pa[NP][REP], pL[REP];
     __shared__ float qs[REP][D];
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KV
     const int base0 = wave * NG * KPW;
     if (base0 < t.ctx_len) fetch(base0, kA, vA);
     // ---- phase 1: k, v and the REP query heads of this kv group (one wave per head, lane = rotation pair)
-    for (int hh = wave; hh < 2 + REP; hh += 4) {
+    for (int hh = wave; hh < 2 + REP; hh += NW) {
         const bool is_k = hh == 0, is_v = hh == 1;
         const int head = is_k ? a.nh + g : (is_v ? a.nh + a.nkv + g : g * REP + (hh - 2));
         const bool act = lane < HALF;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KV
         }
     };
     {
-        constexpr int STEP = 4 * NG * KPW;
+        constexpr int STEP = NW * NG * KPW;
         int base = base0;
         while (base < t.ctx_len) {
             if (base + STEP < t.ctx_len) fetch(base + STEP, kB, vB);
@@ -336,6 +337,15 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KV
             const float aw = expf(m - M);
             pa[part][h] = aw;
             L = row16_sum(aw * pl[part][h]);
+        } else if constexpr (NP == 32 || NP == 64) {  // the partials of a head sit in NP consecutive lanes of one wave
+            M = m;
+#pragma unroll
+            for (int off = NP / 2; off > 0; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
+            const float aw = expf(m - M);
+            pa[part][h] = aw;
+            L = aw * pl[part][h];
+#pragma unroll
+            for (int off = NP / 2; off > 0; off >>= 1) L += __shfl_xor(L, off, 64);
         } else {
             M = pm[0][h];
             for (int q = 1; q < NP; ++q) M = fmaxf(M, pm[q][h]);
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(QkvPostArgs a, KV
         if (part == 0) pL[h] = L;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < REP * D; idx += 256) {
+    for (int idx = threadIdx.x; idx < REP * D; idx += NW * 64) {
         const int h = idx / D, dd = idx % D;
         float acc = 0.f;
 #pragma unroll
@@ -496,15 +506,32 @@ static bool attn_small_enabled() {
     return on;
 }
 
+// QTTS_ATTN_WAVES=4 / 8: waves per block of the launches over growing contexts, whatever else shares the GPU
+static int attn_long_waves(bool shared) {
+    static const int nw = getenv("QTTS_ATTN_WAVES") ? atoi(getenv("QTTS_ATTN_WAVES")) : 0;
+    return nw == 4 || nw == 8 ? nw : (shared ? 4 : 8);
+}
+
 template <typename T, int D, int NG>
 static void launch_attn_decode_ng(hipStream_t st, const QkvPostArgs& a, const KVView& kv, float scale, T* out, long out_lo) {
     const int rep = a.nh / kv.nkv;
     dim3 grid(a.M, kv.nkv), block(256);
+    // A block walks its token's keys NW * 64 / (D / 8) at a time with two fetches in flight per wave, and the grid (tokens x
+    // kv heads) is only two blocks per CU: with contexts of hundreds of keys the walk is bound by the bytes in flight.  A
+    // stream that has the GPU to itself takes eight waves per block for such launches (frame of 64 rows alone 4.48 -> 4.42 ms);
+    // with three sessions in flight the other sessions' kernels fill the CUs and four waves measured 3.7 % more audio-s/s.
+    // The code predictor's passes (at most 17 keys, one position for every token) keep four.
+    if constexpr (D == 128 && NG == 1) {
+        if (rep == 2 && a.uni_len == 0 && attn_long_waves(a.small != 0) == 8) {
+            hipLaunchKernelGGL((attention_decode_kernel<T, D, 2, NG, 8>), grid, dim3(512), 0, st, a, kv, scale, out, out_lo);
+            return;
+        }
+    }
     switch (rep) {
-        case 1: hipLaunchKernelGGL((attention_decode_kernel<T, D, 1, NG>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
-        case 2: hipLaunchKernelGGL((attention_decode_kernel<T, D, 2, NG>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
-        case 4: hipLaunchKernelGGL((attention_decode_kernel<T, D, 4, NG>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
-        case 8: hipLaunchKernelGGL((attention_decode_kernel<T, D, 8, NG>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
+        case 1: hipLaunchKernelGGL((attention_decode_kernel<T, D, 1, NG, 4>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
+        case 2: hipLaunchKernelGGL((attention_decode_kernel<T, D, 2, NG, 4>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
+        case 4: hipLaunchKernelGGL((attention_decode_kernel<T, D, 4, NG, 4>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
+        case 8: hipLaunchKernelGGL((attention_decode_kernel<T, D, 8, NG, 4>), grid, block, 0, st, a, kv, scale, out, out_lo); break;
         default: throw Error(ERR_SHAPE, "attention: heads per kv head must be 1, 2, 4 or 8");
     }
 }

@@ -190,7 +190,8 @@ struct QkvPostArgs {
     int M, nh, nkv, d, layer;
     float* q_out;        // [Mpad][nh d] f32
     int uni_len = 0;     // decode launches only: > 0 = every token m is Tok{m, uni_len - 1, 0, uni_len}; toks is not read
-    int small = 0;       // decode launches with uni_len <= 16: 1 = the one-wave-per-(token, kv head) kernel may take them (k_attn.hip)
+    int small = 0;       // 1 = several decode streams share the GPU: launches with uni_len <= 16 may take the one-wave-per-(token, kv head)
+                         // kernel and growing contexts keep four waves per block (k_attn.hip)
     int out_packed = 0;  // decode launches, bf16 only: > 0 = the attention output is a packed [64][out_packed] matrix (device_utils.hpp packed_elem)
 };
 void launch_qkv_post(hipStream_t st, int dtype, const QkvPostArgs& a, const KVView& kv);

@@ -266,6 +266,31 @@ def test_one_wave_short_context_attention_agrees_with_the_general_kernel(tmp_pat
     _cp_logits_agree(res[0], res[1], 5)
 
 
+def test_eight_waves_per_attention_block_agree_with_four(tmp_path):
+    """A stream that has the GPU to itself walks the talker's growing contexts with eight waves per attention block instead of
+    four: the same online softmax over twice the partial results, so the talker's logits agree to bf16 rounding for as long as
+    the sampled histories agree."""
+    import numpy as np
+    res = []
+    for i, env in enumerate(({"QTTS_TUNE": "alone"}, {"QTTS_TUNE": "alone", "QTTS_ATTN_WAVES": "4"})):
+        path = str(tmp_path / f"a{i}.npz")
+        r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + FRAG_SCRIPT, path], env=dict(os.environ, **env), capture_output=True,
+                           text=True, timeout=280)
+        assert r.returncode == 0 and "saved" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+        res.append(np.load(path))
+    a, b = res
+    assert not np.array_equal(a["logits"], b["logits"]), "the switch selected the same kernel twice"
+    checked = 0
+    for row in range(a["codes"].shape[0]):
+        for t in range(a["codes"].shape[1]):
+            if t > 0 and not (a["codes"][row][t - 1] == b["codes"][row][t - 1]).all():
+                break
+            err = np.abs(a["logits"][row][t] - b["logits"][row][t]).max()
+            assert err <= 2e-2, f"row {row} frame {t}: {err:.4f}"
+            checked += 1
+    assert checked >= 2 * a["codes"].shape[0]
+
+
 def test_fragment_order_passes_at_more_than_64_rows(tmp_path):
     """70 rows: the fragment-order GEMMs then run on 128 packed rows (eight row tiles instead of four); same check as at 5 rows."""
     import numpy as np
