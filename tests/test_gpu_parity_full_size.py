@@ -262,17 +262,21 @@ def test_headline_shape_bf16_logits_of_a_batch_of_64(with_session):
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_reference_default_codec_against_the_oracle(dtype):
-    """Reference-default codec shapes (1024-wide transformer, 1536-channel vocoder, x1920): rows of 104, 12 and 9 frames against
-    the oracle's decode of identical codes.  The long row crosses the 72-key attention window and spans two 64-query tiles of
-    the banded attention kernel."""
+    """Reference-default codec shapes (1024-wide transformer, 1536-channel vocoder, x1920): rows of 104, 12, 9, 1, 2 and 0
+    frames against the oracle's decode of identical codes.  The long row crosses the 72-key attention window and spans two
+    64-query tiles of the banded attention kernel; the rows of one and two frames are shorter than a row tile of the fused
+    vocoder units at every rate (their first tile is also their last), the empty row yields no samples."""
     from oracle import bind
     m, o, cfg, ccfg, tmpl = _pair(bind, "S17", dtype, talker=False, codec=True)
     try:
         rng = np.random.default_rng(5)
-        codes = rng.integers(0, 2048, (3, 104, 16)).astype(np.uint32)
-        lens = [104, 12, 9]
+        codes = rng.integers(0, 2048, (6, 104, 16)).astype(np.uint32)
+        lens = [104, 12, 9, 1, 2, 0]
         wavs = m.decode_codes(codes, lens)
         for b, L in enumerate(lens):
+            if L == 0:
+                assert len(wavs[b]) == 0
+                continue
             ref = o.codec_decode(codes[b, :L])
             assert len(ref) == len(wavs[b]) == 1920 * L - 555
             s = snr_db(ref, wavs[b])
