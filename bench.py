@@ -319,6 +319,7 @@ def main():
         first_ms = []
 
         cb_ms = []
+        cb_parts = []
 
         def on_first(codes):
             t_cb = time.perf_counter()
@@ -326,10 +327,14 @@ def main():
             # a row that already produced EOS (a cb0 outside the codebook) has no audio from that frame on: feed silence codes
             done = np.maximum.accumulate(codes[:, :, 0] >= csize, axis=1)
             codes = np.where(done[:, :, None], 0, codes).astype(np.uint32)
-            with mod.open_codec_stream(codes.shape[0], codes.shape[1]) as cs:
-                cs.push(codes)
+            cs = mod.open_codec_stream(codes.shape[0], codes.shape[1])
+            t_o = time.perf_counter()
+            cs.push(codes)
             first_ms.append((time.perf_counter() - t_s) * 1e3)
+            t_p = time.perf_counter()
+            cs.close()
             cb_ms.append((time.perf_counter() - t_cb) * 1e3)
+            cb_parts.append(((t_o - t_cb) * 1e3, (t_p - t_o) * 1e3, (time.perf_counter() - t_p) * 1e3, mod.codec_device_ms()))
 
         stream_first = not args.no_codec and 2 < args.first_frames < args.frames
         out = mod.generate(reqs, sampling, args.frames, use_graph=not args.no_graph, first_frames=args.first_frames if stream_first else 0,
@@ -338,9 +343,10 @@ def main():
         wavs = [] if args.no_codec else mod.decode_output(out)
         if record and os.environ.get("QTTS_BENCH_TIMING"):   # where a step's wall time goes beyond the device phases (stderr)
             t_d = time.perf_counter()
+            parts = " / ".join("%.1f" % v for v in (cb_parts[0] if cb_parts else ()))
             print(f"step: generate wall {(t_g - t_s) * 1e3:.1f} ms (device prefill {mod.last_timing['prefill_ms']:.1f} + frames "
                   f"{mod.last_timing['frames_ms']:.1f}), first-chunk callback at {first_ms[0] if first_ms else 0:.1f} ms, "
-                  f"(the callback took {cb_ms[0] if cb_ms else 0:.1f} ms), decode wall {(t_d - t_g) * 1e3:.1f} ms (device {0.0 if args.no_codec else mod.codec_device_ms():.1f})", file=sys.stderr)
+                  f"(the callback took {cb_ms[0] if cb_ms else 0:.1f} ms: open / push / close / push on the device {parts}), decode wall {(t_d - t_g) * 1e3:.1f} ms (device {0.0 if args.no_codec else mod.codec_device_ms():.1f})", file=sys.stderr)
         if record:
             with lock:
                 stats["prefill_ms"] += mod.last_timing["prefill_ms"]

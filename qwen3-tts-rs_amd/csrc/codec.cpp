@@ -61,6 +61,10 @@ struct CodecScratch {
     Workspace ws;
     StackW xf;
     DevBuf kv, toks, tiles, meta, codes, A, Bf, R, Rf, Rf2, acc, wav;
+    // the buffers of the last streaming session that was closed on this handle, for the next one to take over: a hipFree waits
+    // for every queue of the GPU to drain (15-60 ms with other sessions decoding), a session per utterance batch would pay it
+    // every time
+    DevBuf spare_kv, spare_latent;
 };
 
 static CodecScratch& codec_scratch(Model& m) {
@@ -922,8 +926,14 @@ CodecStream* codec_stream_open(Model& m, int B, int max_chunk) {
     sc->ring_pages = pages;
     const size_t es = dtype_size(m.dtype);
     const size_t page_elems = (size_t)2 * c.kv_heads * PAGE * c.head_dim;
-    sc->kv.alloc((size_t)c.layers * ((size_t)B + 1) * pages * page_elems * es);
-    sc->latent_ctx.alloc((size_t)B * sc->ctx_cap * s.latP * es * 2);  // room for the remainder plane of bf16 runs
+    CodecScratch& w = codec_scratch(m);
+    const size_t kv_bytes = (size_t)c.layers * ((size_t)B + 1) * pages * page_elems * es;
+    const size_t lat_bytes = (size_t)B * sc->ctx_cap * s.latP * es * 2;  // room for the remainder plane of bf16 runs
+    // (neither buffer is read before it is written: a fresh allocation and a handed-down one serve alike)
+    if (w.spare_kv.bytes >= kv_bytes) sc->kv = std::move(w.spare_kv);
+    else sc->kv.alloc(kv_bytes);
+    if (w.spare_latent.bytes >= lat_bytes) sc->latent_ctx = std::move(w.spare_latent);
+    else sc->latent_ctx.alloc(lat_bytes);
     return sc.release();
 }
 
@@ -931,6 +941,11 @@ void codec_stream_close(CodecStream* sc) {
     if (!sc) return;
     (void)hipSetDevice(sc->m->ctx->device);
     (void)hipStreamSynchronize(sc->m->ctx->stream);
+    if (sc->m->codec_scratch) {
+        CodecScratch& w = *sc->m->codec_scratch;
+        if (sc->kv.bytes > w.spare_kv.bytes) std::swap(sc->kv, w.spare_kv);
+        if (sc->latent_ctx.bytes > w.spare_latent.bytes) std::swap(sc->latent_ctx, w.spare_latent);
+    }
     delete sc;
 }
 

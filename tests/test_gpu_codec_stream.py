@@ -40,6 +40,11 @@ def test_stream_equals_whole_decode_f32(golden):
         assert np.abs(wav1[0] - whole[0][:wav1.shape[1]]).max() < 1e-5
         # and against the oracle's whole decode
         assert snr_db(golden["wav_full600_head"], wav[0][:4096]) >= 40.0
+        # a session takes over the device buffers of the one closed before it on the handle: what they still hold (the other
+        # row's keys, values and context) must not reach the samples
+        wav2, _ = _stream(m, codes[::-1].copy(), pushes, 64)
+        for b in range(2):
+            assert np.abs(wav2[b] - whole[1 - b]).max() < 1e-5, b
     finally:
         m.close()
 
