@@ -61,7 +61,7 @@ int main(int argc, char** argv) {
 #endif
             } else {
                 e.mode = mode ? FUSED_SWIGLU : FUSED_PLAIN; e.out_f32 = out; e.ld_out = N; e.act = act; e.act_lo = 0;
-                if (kind == "stream") launch_gemm_stream(st, w, X, K, x_lo, M, N, K, e, tuning_forced() == TUNE_SHARED);
+                if (kind == "stream") launch_gemm_stream(st, w, X, K, x_lo, M, N, K, e);
                 else launch_gemm_full_k(st, w, X, K, x_lo, M, N, K, e);
             }
         };
